@@ -1,0 +1,189 @@
+/* sdr_amd.h -- C ABI of libsdr_amd.so: the MI355X (gfx950) implementation of the erithion/SDR
+ * receive-side hot path (CP removal -> batched FFT -> one-tap equalisation -> max-log QAM
+ * soft demapping), plus the transmit chain / AWGN frame generator / BER counters around it.
+ *
+ * The reference (header-only C++, /root/reference/lib/inc) has no ABI of its own; each entry
+ * point below names the reference interface it stands behind (file:line).  The drop-in C++
+ * headers in include/sdrlib/ keep the reference's own names and call these.
+ *
+ * Conventions
+ *  - Complex data is interleaved (re, im).  "c32" = two fp32 (std::complex<float>), "c64" = two
+ *    fp64 (std::complex<double>).
+ *  - Every function returns SDR_OK (0) or a negative sdr_status; sdr_last_error() returns the
+ *    message of the calling thread's last failure.  A size that is not a power of two yields
+ *    SDR_ERR_NOT_POW2 with exactly the reference's text
+ *    "The sequence size must be of powers of 2" (lib/inc/fft.hpp:92).
+ *  - A context owns one device and one HIP stream.  All work is enqueued on that stream and is
+ *    asynchronous unless the name ends in _host (those copy in, run, copy out, and synchronise).
+ *    One context must not be used from two threads at once; separate contexts are independent.
+ *  - The library never frees or reallocates caller memory.  Device pointers must belong to the
+ *    context's device.
+ *  - There is NO CPU fallback: without a HIP device every compute entry point fails.
+ */
+#ifndef SDR_AMD_H
+#define SDR_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sdr_ctx sdr_ctx;
+
+typedef enum sdr_status {
+    SDR_OK = 0,
+    SDR_ERR_NOT_POW2 = -1,   /* lib/inc/fft.hpp:91-92 */
+    SDR_ERR_INVALID = -2,    /* bad argument (null pointer, cp > input, unknown modulation ...) */
+    SDR_ERR_HIP = -3,        /* a HIP runtime call failed; text carries hipGetErrorString */
+    SDR_ERR_UNSUPPORTED = -4 /* size/mode outside what the kernels cover */
+} sdr_status;
+
+/* Modulation = bits per subcarrier.  e16QAM is the reference's (lib/inc/modulation.hpp:15-68);
+ * the others fill its empty tag structs (:13-14, :70-72) by the same rule: high half of the
+ * index -> I, low half -> Q, per-axis Gray, level = 2*gray_decode(g)-(L-1), norm = 1/sqrt(Es). */
+typedef enum sdr_modulation {
+    SDR_MOD_BPSK = 1,
+    SDR_MOD_QPSK = 2,
+    SDR_MOD_16QAM = 4,
+    SDR_MOD_64QAM = 6,
+    SDR_MOD_256QAM = 8,
+    SDR_MOD_1024QAM = 10
+} sdr_modulation;
+
+/* ---- library / context ------------------------------------------------------------------ */
+const char* sdr_version(void);
+const char* sdr_last_error(void);
+int sdr_device_count(int* count);
+
+/* Creates a context on `device` with a stream of its own. */
+int sdr_create(int device, sdr_ctx** out);
+/* Same, but enqueues on a caller-owned hipStream_t (e.g. torch's current stream). */
+int sdr_create_on_stream(int device, void* hip_stream, sdr_ctx** out);
+void sdr_destroy(sdr_ctx* ctx);
+int sdr_synchronize(sdr_ctx* ctx);
+/* hipStream_t the context enqueues on (for event timing by the caller). */
+void* sdr_stream(sdr_ctx* ctx);
+
+/* ---- R2/R4: fft::fft2 / fft::ifft2 (lib/inc/fft.hpp:176-180, :194-205) --------------------
+ * In-place, batched: `batch` contiguous sequences of `n` complex values in device memory.
+ * Same radix-2 DIT network and the same per-stage twiddle sequence as the reference
+ * (:87-155); inverse also divides by n (:200-202).  n = 0 or 1 succeeds and does nothing (:91). */
+int sdr_fft2_c32(sdr_ctx* ctx, void* d_data, size_t n, size_t batch, int inverse);
+int sdr_fft2_c64(sdr_ctx* ctx, void* d_data, size_t n, size_t batch, int inverse);
+/* Host-memory forms used by the drop-in fft.hpp. */
+int sdr_fft2_host_c32(sdr_ctx* ctx, void* h_data, size_t n, size_t batch, int inverse);
+int sdr_fft2_host_c64(sdr_ctx* ctx, void* h_data, size_t n, size_t batch, int inverse);
+/* The per-stage twiddle table the kernels use: entry (span/2-1+j) = w of butterfly j of the
+ * stage with that span (lib/inc/fft.hpp:113-150), n-1 complex entries, written to host memory. */
+int sdr_twiddle_table_c32(size_t n, int inverse, float* h_out);
+int sdr_twiddle_table_c64(size_t n, int inverse, double* h_out);
+
+/* ---- R1/R5: ofdm::rx / ofdm::tx (lib/inc/ofdm.hpp:37-43, :13-24), batched ------------------
+ * rx: in = n_sym x (n_fft+cp) samples, out = n_sym x n_fft bins (CP skipped on load).
+ * tx: in = n_sym x n_fft bins, out = n_sym x (n_fft+cp) samples (CP = copy of the tail).
+ * cp > n_fft is allowed for tx only as in the reference; rx needs n_fft >= 1. */
+int sdr_ofdm_rx_c32(sdr_ctx* ctx, const void* d_in, size_t n_fft, size_t cp, size_t n_sym, void* d_out);
+int sdr_ofdm_rx_c64(sdr_ctx* ctx, const void* d_in, size_t n_fft, size_t cp, size_t n_sym, void* d_out);
+int sdr_ofdm_tx_c32(sdr_ctx* ctx, const void* d_in, size_t n_fft, size_t cp, size_t n_sym, void* d_out);
+int sdr_ofdm_tx_c64(sdr_ctx* ctx, const void* d_in, size_t n_fft, size_t cp, size_t n_sym, void* d_out);
+int sdr_ofdm_rx_host_c32(sdr_ctx* ctx, const void* h_in, size_t n_fft, size_t cp, size_t n_sym, void* h_out);
+int sdr_ofdm_rx_host_c64(sdr_ctx* ctx, const void* h_in, size_t n_fft, size_t cp, size_t n_sym, void* h_out);
+int sdr_ofdm_tx_host_c32(sdr_ctx* ctx, const void* h_in, size_t n_fft, size_t cp, size_t n_sym, void* h_out);
+int sdr_ofdm_tx_host_c64(sdr_ctx* ctx, const void* h_in, size_t n_fft, size_t cp, size_t n_sym, void* h_out);
+
+/* ---- R6-R8: modulation::to_constl / from_constl / nearest (lib/inc/modulation.hpp:49-112) --
+ * Bit streams are MSB first in groups of `mod` bits (for 16-QAM: high nibble first, :87-91).
+ * to_constl: n_sym symbols from ceil(n_sym*mod/8) bytes.  from_constl: floor(n_sym*mod/8)
+ * bytes of hard decisions (symbols that do not complete a byte are dropped, :103);
+ * decisions follow nearest(): scale by inorm, ascending scan, strict '<' (:52-65). */
+int sdr_to_constl_c32(sdr_ctx* ctx, int mod, const uint8_t* d_bytes, size_t n_sym, void* d_out);
+int sdr_to_constl_c64(sdr_ctx* ctx, int mod, const uint8_t* d_bytes, size_t n_sym, void* d_out);
+int sdr_from_constl_c32(sdr_ctx* ctx, int mod, const void* d_sym, size_t n_sym, uint8_t* d_bytes);
+int sdr_from_constl_c64(sdr_ctx* ctx, int mod, const void* d_sym, size_t n_sym, uint8_t* d_bytes);
+int sdr_to_constl_host_c32(sdr_ctx* ctx, int mod, const uint8_t* h_bytes, size_t n_sym, void* h_out);
+int sdr_to_constl_host_c64(sdr_ctx* ctx, int mod, const uint8_t* h_bytes, size_t n_sym, void* h_out);
+int sdr_from_constl_host_c32(sdr_ctx* ctx, int mod, const void* h_sym, size_t n_sym, uint8_t* h_bytes);
+int sdr_from_constl_host_c64(sdr_ctx* ctx, int mod, const void* h_sym, size_t n_sym, uint8_t* h_bytes);
+/* nearest() per symbol: one uint16 index each. */
+int sdr_nearest_c32(sdr_ctx* ctx, int mod, const void* d_sym, size_t n_sym, uint16_t* d_index);
+/* Host-side description of a constellation: norm, inorm, 2^mod (I,Q) levels. */
+int sdr_constellation_f32(int mod, float* norm, float* inorm, float* table);
+
+/* ---- X1/X2: the fused receive path (no reference counterpart; sits between ofdm::rx,
+ * lib/inc/ofdm.hpp:37-43, and modulation::from_constl, lib/inc/modulation.hpp:96-112) -------
+ * Per OFDM symbol: skip cp samples, FFT (reference network), yhat = y*G_k, u = yhat*inorm,
+ *   LLR_b = (min_{levels with bit 1}(v-l)^2 - min_{levels with bit 0}(v-l)^2) * w_k
+ * (v = the I or Q coordinate of u that carries bit b; positive = bit 0), and the nearest()
+ * hard decision.  Outputs that are NULL are skipped.
+ *   d_llr   n_sym*n_fft*mod fp32, subcarrier-major, bit order = index MSB first (I bits, then Q).
+ *   d_hard  n_sym*n_fft*mod/8 bytes, MSB-first stream over the whole batch.
+ *   d_fft   n_sym*n_fft c32: the un-equalised FFT output (= ofdm::rx).
+ * d_eq / d_llr_weight hold one set of n_fft taps / weights per `sym_per_set` consecutive
+ * symbols (sym_per_set = 0: a single set); NULL d_eq = no equaliser, NULL d_llr_weight = the
+ * scalar llr_weight0.  If d_ref_hard (same layout as d_hard) and d_counters are given, the
+ * kernel also accumulates into d_counters[0..7] (uint64):
+ *   [0] bit errors  [1] bits  [2] subcarrier-symbol errors  [3] subcarrier symbols
+ *   [4] OFDM symbols  [5] sum trunc(min(|LLR|*1024, 2^30))  [6] LLR sign errors  [7] reserved. */
+typedef struct sdr_demod_args {
+    uint32_t struct_size;       /* = sizeof(sdr_demod_args) */
+    uint32_t n_fft;
+    uint32_t cp;
+    uint32_t mod;               /* sdr_modulation */
+    uint64_t n_sym;
+    uint32_t sym_per_set;
+    float llr_weight0;
+    const void* d_rx;           /* n_sym*(n_fft+cp) c32 */
+    const void* d_eq;           /* n_sets*n_fft c32 or NULL */
+    const float* d_llr_weight;  /* n_sets*n_fft or NULL */
+    float* d_llr;
+    uint8_t* d_hard;
+    void* d_fft;
+    const uint8_t* d_ref_hard;
+    uint64_t* d_counters;
+} sdr_demod_args;
+int sdr_ofdm_demod_c32(sdr_ctx* ctx, const sdr_demod_args* args);
+
+/* Equaliser taps and LLR weights from a channel estimate H (n values):
+ *   p = |H|^2, G = conj(H)/p, w = norm^2 * p * inv_n0. */
+int sdr_zf_taps_c32(sdr_ctx* ctx, int mod, const void* d_chan, size_t n, float inv_n0, void* d_taps, float* d_weight);
+
+/* Soft demapping alone (X2) on equalised symbols already in memory. */
+int sdr_soft_demap_c32(sdr_ctx* ctx, int mod, const void* d_sym, size_t n_sym, const float* d_weight, float weight0, float* d_llr);
+
+/* ---- X4: device frame generator, AWGN and Monte-Carlo link (no reference counterpart; model:
+ * app/QFDemoWindow.cpp:201-224) --------------------------------------------------------------
+ * Randomness is Philox4x32-10 keyed by `seed` and counted by (global symbol index, subcarrier /
+ * sample index), so results do not depend on how symbols are split over calls or GPUs.
+ * generate: symbols g0..g0+n_sym-1 -> to_constl -> [x H_k] -> tx (IFFT, CP) -> + N(0, sigma^2)
+ * per real component.  d_chan: one set of n_fft values per sym_per_set symbols, first set =
+ * g0/sym_per_set; NULL = flat.  d_tx_bits (optional) = transmitted bits, MSB-first stream. */
+typedef struct sdr_link_args {
+    uint32_t struct_size;
+    uint32_t n_fft;
+    uint32_t cp;
+    uint32_t mod;
+    uint64_t seed;
+    uint64_t first_symbol;      /* g0 */
+    uint64_t n_sym;
+    uint32_t sym_per_set;
+    float sigma;                /* per-component noise standard deviation, time domain */
+    float llr_weight0;          /* ber only */
+    uint32_t reserved;
+    const void* d_chan;         /* generate only */
+    void* d_rx;                 /* generate only: n_sym*(n_fft+cp) c32 */
+    uint8_t* d_tx_bits;         /* generate only, optional */
+    uint64_t* d_counters;       /* ber only: 8 x uint64, accumulated into */
+} sdr_link_args;
+int sdr_link_generate_c32(sdr_ctx* ctx, const sdr_link_args* args);
+/* generate -> demodulate -> count entirely on the device; nothing but counters touches HBM. */
+int sdr_link_ber_c32(sdr_ctx* ctx, const sdr_link_args* args);
+
+/* Host-visible pieces of the generator, for tests. */
+int sdr_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDR_AMD_H */

@@ -1,0 +1,142 @@
+"""ctypes binding of libsdr_amd.so (include/sdr_amd.h).
+
+The library is the product; this module is plumbing.  There is no CPU fallback: if the shared
+object is missing, importing any compute entry point raises, and every call on a machine
+without a HIP device fails with the library's own error text.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_size_t, c_uint8, c_uint16, c_uint32, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsdr_amd.so")
+
+SDR_OK = 0
+SDR_ERR_NOT_POW2 = -1
+SDR_ERR_INVALID = -2
+SDR_ERR_HIP = -3
+SDR_ERR_UNSUPPORTED = -4
+
+POW2_MESSAGE = "The sequence size must be of powers of 2"  # reference lib/inc/fft.hpp:92
+
+
+class SdrError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libsdr_amd error {code}: {message}")
+        self.code = code
+        self.message = message
+
+
+class DemodArgs(Structure):
+    _fields_ = [
+        ("struct_size", c_uint32),
+        ("n_fft", c_uint32),
+        ("cp", c_uint32),
+        ("mod", c_uint32),
+        ("n_sym", c_uint64),
+        ("sym_per_set", c_uint32),
+        ("llr_weight0", c_float),
+        ("d_rx", c_void_p),
+        ("d_eq", c_void_p),
+        ("d_llr_weight", c_void_p),
+        ("d_llr", c_void_p),
+        ("d_hard", c_void_p),
+        ("d_fft", c_void_p),
+        ("d_ref_hard", c_void_p),
+        ("d_counters", c_void_p),
+    ]
+
+
+class LinkArgs(Structure):
+    _fields_ = [
+        ("struct_size", c_uint32),
+        ("n_fft", c_uint32),
+        ("cp", c_uint32),
+        ("mod", c_uint32),
+        ("seed", c_uint64),
+        ("first_symbol", c_uint64),
+        ("n_sym", c_uint64),
+        ("sym_per_set", c_uint32),
+        ("sigma", c_float),
+        ("llr_weight0", c_float),
+        ("reserved", c_uint32),
+        ("d_chan", c_void_p),
+        ("d_rx", c_void_p),
+        ("d_tx_bits", c_void_p),
+        ("d_counters", c_void_p),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/sdr_amd.h declares
+SIGNATURES = {
+    "sdr_version": (c_char_p, []),
+    "sdr_last_error": (c_char_p, []),
+    "sdr_device_count": (c_int, [POINTER(c_int)]),
+    "sdr_create": (c_int, [c_int, POINTER(c_void_p)]),
+    "sdr_create_on_stream": (c_int, [c_int, c_void_p, POINTER(c_void_p)]),
+    "sdr_destroy": (None, [c_void_p]),
+    "sdr_synchronize": (c_int, [c_void_p]),
+    "sdr_stream": (c_void_p, [c_void_p]),
+    "sdr_fft2_c32": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_int]),
+    "sdr_fft2_c64": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_int]),
+    "sdr_fft2_host_c32": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_int]),
+    "sdr_fft2_host_c64": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_int]),
+    "sdr_twiddle_table_c32": (c_int, [c_size_t, c_int, c_void_p]),
+    "sdr_twiddle_table_c64": (c_int, [c_size_t, c_int, c_void_p]),
+    "sdr_ofdm_rx_c32": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_void_p]),
+    "sdr_ofdm_rx_c64": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_void_p]),
+    "sdr_ofdm_tx_c32": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_void_p]),
+    "sdr_ofdm_tx_c64": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_void_p]),
+    "sdr_ofdm_rx_host_c32": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_void_p]),
+    "sdr_ofdm_rx_host_c64": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_void_p]),
+    "sdr_ofdm_tx_host_c32": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_void_p]),
+    "sdr_ofdm_tx_host_c64": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_void_p]),
+    "sdr_to_constl_c32": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "sdr_to_constl_c64": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "sdr_from_constl_c32": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "sdr_from_constl_c64": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "sdr_to_constl_host_c32": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "sdr_to_constl_host_c64": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "sdr_from_constl_host_c32": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "sdr_from_constl_host_c64": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "sdr_nearest_c32": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "sdr_constellation_f32": (c_int, [c_int, POINTER(c_float), POINTER(c_float), c_void_p]),
+    "sdr_ofdm_demod_c32": (c_int, [c_void_p, POINTER(DemodArgs)]),
+    "sdr_zf_taps_c32": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_float, c_void_p, c_void_p]),
+    "sdr_soft_demap_c32": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p, c_float, c_void_p]),
+    "sdr_link_generate_c32": (c_int, [c_void_p, POINTER(LinkArgs)]),
+    "sdr_link_ber_c32": (c_int, [c_void_p, POINTER(LinkArgs)]),
+    "sdr_philox4x32_10": (c_int, [POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32)]),
+}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Loads libsdr_amd.so (built in-tree by __graft_entry__.build() / sdr_amd/csrc/Makefile)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `make -C sdr_amd/csrc` (hipcc, gfx950). "
+            "sdr_amd has no CPU fallback."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().sdr_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int) -> None:
+    if rc != SDR_OK:
+        raise SdrError(rc, last_error())

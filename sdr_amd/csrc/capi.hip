@@ -1,0 +1,232 @@
+// capi.hip -- the extern "C" surface declared in include/sdr_amd.h: argument checks, choice
+// between the tuned fused kernels and the generic engines, host-memory convenience forms.
+#include "common.hpp"
+#include "kernels.hpp"
+#include "qam.hpp"
+#include "rng.hpp"
+
+#include <cmath>
+
+using namespace sdr;
+
+namespace {
+
+int fft2_device(sdr_ctx* ctx, bool is_double, void* d_data, size_t n, size_t batch, int inverse)
+{
+    SDR_TRY(ensure_device(ctx));
+    if (n <= 1 || batch == 0) return SDR_OK;                       // lib/inc/fft.hpp:91: sizes 0 and 1 pass untouched
+    if (!is_pow2(n)) return fail(SDR_ERR_NOT_POW2, "%s", kPow2Message);
+    if (!d_data) return fail(SDR_ERR_INVALID, "null device pointer");
+    return is_double ? fft_generic_f64(ctx, d_data, d_data, n, inverse != 0, n, 0, n, 0, 0, batch)
+                     : fft_generic_f32(ctx, d_data, d_data, n, inverse != 0, n, 0, n, 0, 0, batch);
+}
+
+int ofdm_rx_device(sdr_ctx* ctx, bool is_double, const void* d_in, size_t n_fft, size_t cp, size_t n_sym, void* d_out)
+{
+    SDR_TRY(ensure_device(ctx));
+    if (n_sym == 0 || n_fft == 0) return SDR_OK;
+    if (!is_pow2(n_fft)) return fail(SDR_ERR_NOT_POW2, "%s", kPow2Message);
+    if (!d_in || !d_out) return fail(SDR_ERR_INVALID, "null device pointer");
+    if (!is_double && n_fft <= 0xFFFFFFFFu && cp <= 0xFFFFFFFFu && rx_fused_supported(static_cast<uint32_t>(n_fft), 0))
+        return rx_fft_only_launch(ctx, d_in, static_cast<uint32_t>(n_fft), static_cast<uint32_t>(cp), n_sym, d_out);
+    return is_double ? fft_generic_f64(ctx, d_in, d_out, n_fft, false, n_fft + cp, cp, n_fft, 0, 0, n_sym)
+                     : fft_generic_f32(ctx, d_in, d_out, n_fft, false, n_fft + cp, cp, n_fft, 0, 0, n_sym);
+}
+
+int ofdm_tx_device(sdr_ctx* ctx, bool is_double, const void* d_in, size_t n_fft, size_t cp, size_t n_sym, void* d_out)
+{
+    SDR_TRY(ensure_device(ctx));
+    if (n_sym == 0) return SDR_OK;
+    if (n_fft != 0 && !is_pow2(n_fft)) return fail(SDR_ERR_NOT_POW2, "%s", kPow2Message);
+    if (cp > n_fft) return fail(SDR_ERR_INVALID, "batched tx needs cp (%zu) <= n_fft (%zu)", cp, n_fft);
+    if (n_fft == 0) return SDR_OK;
+    if (!d_in || !d_out) return fail(SDR_ERR_INVALID, "null device pointer");
+    return is_double ? fft_generic_f64(ctx, d_in, d_out, n_fft, true, n_fft, 0, n_fft + cp, cp, cp, n_sym)
+                     : fft_generic_f32(ctx, d_in, d_out, n_fft, true, n_fft, 0, n_fft + cp, cp, cp, n_sym);
+}
+
+// copy in -> run -> copy out -> synchronise
+template <typename Fn>
+int with_host_buffers(sdr_ctx* ctx, const void* h_in, size_t in_bytes, void* h_out, size_t out_bytes, bool in_place, Fn&& fn)
+{
+    SDR_TRY(ensure_device(ctx));
+    void* d_in = nullptr;
+    void* d_out = nullptr;
+    if (in_bytes) SDR_TRY(get_staging(ctx, 6, in_bytes, &d_in));
+    if (in_place) d_out = d_in;
+    else if (out_bytes) SDR_TRY(get_staging(ctx, 7, out_bytes, &d_out));
+    if (in_bytes) SDR_HIP(hipMemcpyAsync(d_in, h_in, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    SDR_TRY(fn(d_in, d_out));
+    if (out_bytes) SDR_HIP(hipMemcpyAsync(h_out, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    SDR_HIP(hipStreamSynchronize(ctx->stream));
+    return SDR_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int sdr_fft2_c32(sdr_ctx* ctx, void* d_data, size_t n, size_t batch, int inverse) { return fft2_device(ctx, false, d_data, n, batch, inverse); }
+int sdr_fft2_c64(sdr_ctx* ctx, void* d_data, size_t n, size_t batch, int inverse) { return fft2_device(ctx, true, d_data, n, batch, inverse); }
+
+int sdr_fft2_host_c32(sdr_ctx* ctx, void* h_data, size_t n, size_t batch, int inverse)
+{
+    if (n <= 1 || batch == 0) return SDR_OK;
+    if (!is_pow2(n)) return fail(SDR_ERR_NOT_POW2, "%s", kPow2Message);
+    if (!h_data) return fail(SDR_ERR_INVALID, "null host pointer");
+    const size_t bytes = n * batch * 2 * sizeof(float);
+    return with_host_buffers(ctx, h_data, bytes, h_data, bytes, true, [&](void* d_in, void*) { return fft2_device(ctx, false, d_in, n, batch, inverse); });
+}
+int sdr_fft2_host_c64(sdr_ctx* ctx, void* h_data, size_t n, size_t batch, int inverse)
+{
+    if (n <= 1 || batch == 0) return SDR_OK;
+    if (!is_pow2(n)) return fail(SDR_ERR_NOT_POW2, "%s", kPow2Message);
+    if (!h_data) return fail(SDR_ERR_INVALID, "null host pointer");
+    const size_t bytes = n * batch * 2 * sizeof(double);
+    return with_host_buffers(ctx, h_data, bytes, h_data, bytes, true, [&](void* d_in, void*) { return fft2_device(ctx, true, d_in, n, batch, inverse); });
+}
+
+int sdr_ofdm_rx_c32(sdr_ctx* ctx, const void* d_in, size_t n_fft, size_t cp, size_t n_sym, void* d_out) { return ofdm_rx_device(ctx, false, d_in, n_fft, cp, n_sym, d_out); }
+int sdr_ofdm_rx_c64(sdr_ctx* ctx, const void* d_in, size_t n_fft, size_t cp, size_t n_sym, void* d_out) { return ofdm_rx_device(ctx, true, d_in, n_fft, cp, n_sym, d_out); }
+int sdr_ofdm_tx_c32(sdr_ctx* ctx, const void* d_in, size_t n_fft, size_t cp, size_t n_sym, void* d_out) { return ofdm_tx_device(ctx, false, d_in, n_fft, cp, n_sym, d_out); }
+int sdr_ofdm_tx_c64(sdr_ctx* ctx, const void* d_in, size_t n_fft, size_t cp, size_t n_sym, void* d_out) { return ofdm_tx_device(ctx, true, d_in, n_fft, cp, n_sym, d_out); }
+
+#define SDR_OFDM_HOST(NAME, DEVFN, IS_DOUBLE, ELEM, IN_LEN, OUT_LEN)                                                      \
+    int NAME(sdr_ctx* ctx, const void* h_in, size_t n_fft, size_t cp, size_t n_sym, void* h_out)                            \
+    {                                                                                                                    \
+        if (n_sym == 0) return SDR_OK;                                                                                   \
+        if (n_fft != 0 && !is_pow2(n_fft)) return fail(SDR_ERR_NOT_POW2, "%s", kPow2Message);                             \
+        if (!h_in || !h_out) return fail(SDR_ERR_INVALID, "null host pointer");                                           \
+        const size_t in_bytes = n_sym * (IN_LEN) * 2 * sizeof(ELEM);                                                       \
+        const size_t out_bytes = n_sym * (OUT_LEN) * 2 * sizeof(ELEM);                                                     \
+        return with_host_buffers(ctx, h_in, in_bytes, h_out, out_bytes, false,                                             \
+                                 [&](void* d_in, void* d_out) { return DEVFN(ctx, IS_DOUBLE, d_in, n_fft, cp, n_sym, d_out); }); \
+    }
+SDR_OFDM_HOST(sdr_ofdm_rx_host_c32, ofdm_rx_device, false, float, n_fft + cp, n_fft)
+SDR_OFDM_HOST(sdr_ofdm_rx_host_c64, ofdm_rx_device, true, double, n_fft + cp, n_fft)
+SDR_OFDM_HOST(sdr_ofdm_tx_host_c32, ofdm_tx_device, false, float, n_fft, n_fft + cp)
+SDR_OFDM_HOST(sdr_ofdm_tx_host_c64, ofdm_tx_device, true, double, n_fft, n_fft + cp)
+#undef SDR_OFDM_HOST
+
+int sdr_to_constl_c32(sdr_ctx* ctx, int mod, const uint8_t* d_bytes, size_t n_sym, void* d_out)
+{
+    SDR_TRY(ensure_device(ctx));
+    return to_constl_dev(ctx, false, mod, d_bytes, n_sym, d_out);
+}
+int sdr_to_constl_c64(sdr_ctx* ctx, int mod, const uint8_t* d_bytes, size_t n_sym, void* d_out)
+{
+    SDR_TRY(ensure_device(ctx));
+    return to_constl_dev(ctx, true, mod, d_bytes, n_sym, d_out);
+}
+int sdr_from_constl_c32(sdr_ctx* ctx, int mod, const void* d_sym, size_t n_sym, uint8_t* d_bytes)
+{
+    SDR_TRY(ensure_device(ctx));
+    return from_constl_dev(ctx, false, mod, d_sym, n_sym, d_bytes);
+}
+int sdr_from_constl_c64(sdr_ctx* ctx, int mod, const void* d_sym, size_t n_sym, uint8_t* d_bytes)
+{
+    SDR_TRY(ensure_device(ctx));
+    return from_constl_dev(ctx, true, mod, d_sym, n_sym, d_bytes);
+}
+
+static int to_constl_host(sdr_ctx* ctx, bool is_double, int mod, const uint8_t* h_bytes, size_t n_sym, void* h_out)
+{
+    if (!valid_mod(mod)) return fail(SDR_ERR_INVALID, "unknown modulation %d", mod);
+    if (n_sym == 0) return SDR_OK;
+    if (!h_bytes || !h_out) return fail(SDR_ERR_INVALID, "null host pointer");
+    const size_t in_bytes = (n_sym * mod + 7) / 8;
+    const size_t out_bytes = n_sym * 2 * (is_double ? sizeof(double) : sizeof(float));
+    return with_host_buffers(ctx, h_bytes, in_bytes, h_out, out_bytes, false,
+                             [&](void* d_in, void* d_out) { return to_constl_dev(ctx, is_double, mod, static_cast<const uint8_t*>(d_in), n_sym, d_out); });
+}
+static int from_constl_host(sdr_ctx* ctx, bool is_double, int mod, const void* h_sym, size_t n_sym, uint8_t* h_bytes)
+{
+    if (!valid_mod(mod)) return fail(SDR_ERR_INVALID, "unknown modulation %d", mod);
+    const size_t out_bytes = (n_sym * mod) / 8;
+    if (out_bytes == 0) return SDR_OK;
+    if (!h_sym || !h_bytes) return fail(SDR_ERR_INVALID, "null host pointer");
+    const size_t in_bytes = n_sym * 2 * (is_double ? sizeof(double) : sizeof(float));
+    return with_host_buffers(ctx, h_sym, in_bytes, h_bytes, out_bytes, false,
+                             [&](void* d_in, void* d_out) { return from_constl_dev(ctx, is_double, mod, d_in, n_sym, static_cast<uint8_t*>(d_out)); });
+}
+int sdr_to_constl_host_c32(sdr_ctx* ctx, int mod, const uint8_t* h_bytes, size_t n_sym, void* h_out) { return to_constl_host(ctx, false, mod, h_bytes, n_sym, h_out); }
+int sdr_to_constl_host_c64(sdr_ctx* ctx, int mod, const uint8_t* h_bytes, size_t n_sym, void* h_out) { return to_constl_host(ctx, true, mod, h_bytes, n_sym, h_out); }
+int sdr_from_constl_host_c32(sdr_ctx* ctx, int mod, const void* h_sym, size_t n_sym, uint8_t* h_bytes) { return from_constl_host(ctx, false, mod, h_sym, n_sym, h_bytes); }
+int sdr_from_constl_host_c64(sdr_ctx* ctx, int mod, const void* h_sym, size_t n_sym, uint8_t* h_bytes) { return from_constl_host(ctx, true, mod, h_sym, n_sym, h_bytes); }
+
+int sdr_nearest_c32(sdr_ctx* ctx, int mod, const void* d_sym, size_t n_sym, uint16_t* d_index)
+{
+    SDR_TRY(ensure_device(ctx));
+    return nearest_dev(ctx, mod, d_sym, n_sym, d_index);
+}
+
+int sdr_constellation_f32(int mod, float* norm, float* inorm, float* table)
+{
+    if (!valid_mod(mod)) return fail(SDR_ERR_INVALID, "unknown modulation %d", mod);
+    if (!norm || !inorm || !table) return fail(SDR_ERR_INVALID, "null output");
+    const float e = static_cast<float>(grid_energy(mod));
+    *norm = 1.0f / std::sqrt(e);
+    *inorm = std::sqrt(e);
+    const int mi = mod == 1 ? 1 : mod / 2, mq = mod == 1 ? 0 : mod / 2;
+    for (unsigned i = 0; i < (1u << mod); ++i) {
+        const unsigned gi = i >> mq, gq = i & ((1u << mq) - 1u);
+        table[2 * i] = static_cast<float>(2 * static_cast<int>(gray_to_binary(gi)) - ((1 << mi) - 1));
+        table[2 * i + 1] = mq ? static_cast<float>(2 * static_cast<int>(gray_to_binary(gq)) - ((1 << mq) - 1)) : 0.0f;
+    }
+    return SDR_OK;
+}
+
+int sdr_ofdm_demod_c32(sdr_ctx* ctx, const sdr_demod_args* args)
+{
+    SDR_TRY(ensure_device(ctx));
+    if (!args) return fail(SDR_ERR_INVALID, "null args");
+    if (args->struct_size != sizeof(sdr_demod_args)) return fail(SDR_ERR_INVALID, "sdr_demod_args.struct_size %u != %zu", args->struct_size, sizeof(sdr_demod_args));
+    const sdr_demod_args& a = *args;
+    if (!valid_mod(static_cast<int>(a.mod))) return fail(SDR_ERR_INVALID, "unknown modulation %u", a.mod);
+    if (a.n_sym == 0 || a.n_fft == 0) return SDR_OK;
+    if (!is_pow2(a.n_fft)) return fail(SDR_ERR_NOT_POW2, "%s", kPow2Message);
+    if (!a.d_rx) return fail(SDR_ERR_INVALID, "null d_rx");
+    if ((a.d_ref_hard != nullptr) != (a.d_counters != nullptr)) return fail(SDR_ERR_INVALID, "d_ref_hard and d_counters must be given together");
+    if (rx_fused_supported(a.n_fft, a.mod)) return rx_fused_launch(ctx, a);
+    // generic sizes: reference-network FFT into memory, then the element-wise back end
+    void* d_fft = a.d_fft;
+    if (!d_fft) SDR_TRY(get_staging(ctx, 5, size_t(a.n_sym) * a.n_fft * sizeof(float2), &d_fft));
+    SDR_TRY(fft_generic_f32(ctx, a.d_rx, d_fft, a.n_fft, false, size_t(a.n_fft) + a.cp, a.cp, a.n_fft, 0, 0, a.n_sym));
+    return demap_after_fft(ctx, a, d_fft);
+}
+
+int sdr_zf_taps_c32(sdr_ctx* ctx, int mod, const void* d_chan, size_t n, float inv_n0, void* d_taps, float* d_weight)
+{
+    SDR_TRY(ensure_device(ctx));
+    return zf_taps_dev(ctx, mod, d_chan, n, inv_n0, d_taps, d_weight);
+}
+
+int sdr_soft_demap_c32(sdr_ctx* ctx, int mod, const void* d_sym, size_t n_sym, const float* d_weight, float weight0, float* d_llr)
+{
+    SDR_TRY(ensure_device(ctx));
+    return soft_demap_dev(ctx, mod, d_sym, n_sym, d_weight, weight0, d_llr);
+}
+
+int sdr_link_generate_c32(sdr_ctx* ctx, const sdr_link_args* args)
+{
+    SDR_TRY(ensure_device(ctx));
+    if (!args) return fail(SDR_ERR_INVALID, "null args");
+    return link_generate(ctx, *args);
+}
+
+int sdr_link_ber_c32(sdr_ctx* ctx, const sdr_link_args* args)
+{
+    SDR_TRY(ensure_device(ctx));
+    if (!args) return fail(SDR_ERR_INVALID, "null args");
+    return link_ber(ctx, *args);
+}
+
+int sdr_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    if (!ctr || !key || !out) return fail(SDR_ERR_INVALID, "null pointer");
+    const Philox4 r = philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1]);
+    for (int i = 0; i < 4; ++i) out[i] = r.v[i];
+    return SDR_OK;
+}
+
+} // extern "C"

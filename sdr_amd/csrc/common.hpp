@@ -1,0 +1,70 @@
+// common.hpp -- context, error reporting and launch helpers shared by the HIP sources.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <tuple>
+#include <vector>
+
+#include "sdr_amd.h"
+
+namespace sdr {
+
+constexpr const char* kPow2Message = "The sequence size must be of powers of 2";   // reference lib/inc/fft.hpp:92
+
+void set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+int fail(sdr_status code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+int fail_hip(hipError_t err, const char* what);
+
+#define SDR_HIP(expr)                                            \
+    do {                                                         \
+        hipError_t sdr_hip_err_ = (expr);                        \
+        if (sdr_hip_err_ != hipSuccess) return ::sdr::fail_hip(sdr_hip_err_, #expr); \
+    } while (0)
+
+#define SDR_TRY(expr)                 \
+    do {                              \
+        int sdr_rc_ = (expr);         \
+        if (sdr_rc_ != SDR_OK) return sdr_rc_; \
+    } while (0)
+
+inline bool is_pow2(size_t n) { return n != 0 && (n & (n - 1)) == 0; }
+inline unsigned ilog2(size_t n) { unsigned l = 0; while ((size_t(1) << l) < n) ++l; return l; }
+
+struct Staging {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+};
+
+} // namespace sdr
+
+// The opaque context of the C ABI: one device, one stream, cached twiddle tables, staging.
+struct sdr_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int num_cu = 0;
+    size_t lds_max = 0;   // bytes of LDS one workgroup may use
+    // key: (n, inverse, is_double) -> device table of n-1 complex twiddles
+    std::map<std::tuple<size_t, int, int>, void*> twiddles;
+    sdr::Staging stage[8];
+    uint64_t* d_scratch_counters = nullptr;
+};
+
+namespace sdr {
+
+int ensure_device(sdr_ctx* ctx);
+// Device pointer to the reference-recurrence twiddle table for length n (n >= 2, power of two).
+int get_twiddles(sdr_ctx* ctx, size_t n, bool inverse, bool is_double, const void** d_table);
+int get_staging(sdr_ctx* ctx, int slot, size_t bytes, void** ptr);
+
+// Host-side generation of the reference's per-stage twiddle sequence (lib/inc/fft.hpp:113-150).
+void make_twiddles_f32(size_t n, bool inverse, float* out);
+void make_twiddles_f64(size_t n, bool inverse, double* out);
+
+} // namespace sdr

@@ -1,0 +1,280 @@
+// demap.hip -- element-wise constellation kernels: to_constl / from_constl / nearest
+// (reference lib/inc/modulation.hpp:49-112), soft demapping and the zero-forcing tap helper
+// (no reference counterpart), and the generic-size back end of the fused receive path.
+#include "common.hpp"
+#include "kernels.hpp"
+#include "qam.hpp"
+
+#include <cmath>
+
+namespace sdr {
+
+namespace {
+
+constexpr unsigned kThreads = 256;
+
+inline unsigned grid_for(sdr_ctx* ctx, size_t work)
+{
+    size_t blocks = (work + kThreads - 1) / kThreads;
+    const size_t cap = size_t(ctx->num_cu) * 16;
+    if (blocks > cap) blocks = cap;
+    if (blocks == 0) blocks = 1;
+    return static_cast<unsigned>(blocks);
+}
+
+// MSB-first bit field of `nbits` (<= 16) starting at stream bit `pos`; touches only the bytes
+// that hold those bits.
+__device__ inline unsigned stream_bits(const uint8_t* __restrict__ s, size_t pos, int nbits)
+{
+    const size_t first = pos >> 3;
+    const size_t last = (pos + nbits - 1) >> 3;
+    unsigned acc = 0;
+    for (size_t b = first; b <= last; ++b) acc = (acc << 8) | s[b];
+    const unsigned span_bits = static_cast<unsigned>(last - first + 1) * 8u;
+    const unsigned shift = span_bits - static_cast<unsigned>(pos & 7) - static_cast<unsigned>(nbits);
+    return (acc >> shift) & ((1u << nbits) - 1u);
+}
+
+template <typename T, int MI, int MQ>
+__global__ void to_constl_kernel(const uint8_t* __restrict__ bytes, size_t n_sym, T norm, T* __restrict__ out)
+{
+    constexpr int BPS = MI + MQ;
+    for (size_t k = blockIdx.x * size_t(blockDim.x) + threadIdx.x; k < n_sym; k += size_t(gridDim.x) * blockDim.x) {
+        const unsigned idx = stream_bits(bytes, k * BPS, BPS);
+        const unsigned gi = idx >> MQ, gq = idx & ((1u << MQ) - 1u);
+        T li = T(0), lq = T(0);
+#pragma unroll
+        for (unsigned g = 0; g < (1u << MI); ++g) li = (g == gi) ? axis_level<T, MI>(g) : li;
+#pragma unroll
+        for (unsigned g = 0; g < (1u << MQ); ++g) lq = (g == gq) ? axis_level<T, MQ>(g) : lq;
+        out[2 * k] = li * norm;        // table[idx] * norm: complex * real (modulation.hpp:90-91)
+        out[2 * k + 1] = lq * norm;
+    }
+}
+
+template <typename T, int MI, int MQ>
+__global__ void nearest_kernel(const T* __restrict__ sym, size_t n_sym, T inorm, uint16_t* __restrict__ index)
+{
+    for (size_t k = blockIdx.x * size_t(blockDim.x) + threadIdx.x; k < n_sym; k += size_t(gridDim.x) * blockDim.x)
+        index[k] = static_cast<uint16_t>(demap_point<T, MI, MQ, false, true>(sym[2 * k], sym[2 * k + 1], inorm, T(0), nullptr));
+}
+
+// One thread per output byte: gathers the bits of the symbols that overlap it.
+__global__ void pack_kernel(const uint16_t* __restrict__ index, size_t n_sym, int bps, size_t n_bytes, uint8_t* __restrict__ out)
+{
+    for (size_t b = blockIdx.x * size_t(blockDim.x) + threadIdx.x; b < n_bytes; b += size_t(gridDim.x) * blockDim.x) {
+        unsigned v = 0;
+        for (int i = 0; i < 8; ++i) {
+            const size_t pos = b * 8 + i;
+            const size_t k = pos / bps;
+            const int within = static_cast<int>(pos - k * bps);
+            const unsigned bit = (k < n_sym) ? ((index[k] >> (bps - 1 - within)) & 1u) : 0u;
+            v = (v << 1) | bit;
+        }
+        out[b] = static_cast<uint8_t>(v);
+    }
+}
+
+template <int MI, int MQ>
+__global__ void soft_demap_kernel(const float* __restrict__ sym, size_t n_sym, float inorm, const float* __restrict__ wgt, float w0,
+                                  float* __restrict__ llr)
+{
+    constexpr int BPS = MI + MQ;
+    for (size_t k = blockIdx.x * size_t(blockDim.x) + threadIdx.x; k < n_sym; k += size_t(gridDim.x) * blockDim.x) {
+        float l[BPS];
+        demap_point<float, MI, MQ, true, false>(sym[2 * k], sym[2 * k + 1], inorm, wgt ? wgt[k] : w0, l);
+#pragma unroll
+        for (int b = 0; b < BPS; ++b) llr[k * BPS + b] = l[b];
+    }
+}
+
+__global__ void zf_taps_kernel(const float2* __restrict__ chan, size_t n, float norm2, float inv_n0, float2* __restrict__ taps, float* __restrict__ wgt)
+{
+    for (size_t k = blockIdx.x * size_t(blockDim.x) + threadIdx.x; k < n; k += size_t(gridDim.x) * blockDim.x) {
+        const float2 h = chan[k];
+        const float p = h.x * h.x + h.y * h.y;
+        taps[k] = make_float2(h.x / p, -h.y / p);
+        wgt[k] = (norm2 * p) * inv_n0;
+    }
+}
+
+__device__ inline unsigned long long wave_sum(unsigned long long v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// Generic-size back end of the fused path: one thread per subcarrier of the whole batch.
+template <int MI, int MQ>
+__global__ void demap_fft_kernel(const float2* __restrict__ fft, uint32_t n_fft, uint64_t n_sym, uint32_t sym_per_set,
+                                 const float2* __restrict__ eq, const float* __restrict__ wgt, float w0, float inorm,
+                                 float* __restrict__ llr, uint16_t* __restrict__ index,
+                                 const uint8_t* __restrict__ ref_bits, unsigned long long* __restrict__ counters)
+{
+    constexpr int BPS = MI + MQ;
+    const size_t total = size_t(n_sym) * n_fft;
+    unsigned long long bit_err = 0, sym_err = 0, abs_q = 0, sign_err = 0, n_done = 0;
+    for (size_t e = blockIdx.x * size_t(blockDim.x) + threadIdx.x; e < total; e += size_t(gridDim.x) * blockDim.x) {
+        const size_t s = e / n_fft;
+        const uint32_t k = static_cast<uint32_t>(e - s * n_fft);
+        const size_t set = sym_per_set ? s / sym_per_set : 0;
+        float2 y = fft[e];
+        if (eq) {
+            const float2 g = eq[set * n_fft + k];
+            const float er = y.x * g.x - y.y * g.y;
+            const float ei = y.x * g.y + y.y * g.x;
+            y.x = er; y.y = ei;
+        }
+        const float w = wgt ? wgt[set * n_fft + k] : w0;
+        float l[BPS];
+        const unsigned idx = demap_point<float, MI, MQ, true, true>(y.x, y.y, inorm, w, l);
+        if (llr) {
+#pragma unroll
+            for (int b = 0; b < BPS; ++b) llr[e * BPS + b] = l[b];
+        }
+        if (index) index[e] = static_cast<uint16_t>(idx);
+        if (counters) {
+            const unsigned ref = stream_bits(ref_bits, e * BPS, BPS);
+            const unsigned diff = ref ^ idx;
+            bit_err += __popc(diff);
+            sym_err += (diff != 0);
+            n_done += 1;
+#pragma unroll
+            for (int b = 0; b < BPS; ++b) {
+                float a = fabsf(l[b]) * 1024.0f;
+                a = (a < 1073741824.0f) ? a : 1073741824.0f;
+                abs_q += static_cast<unsigned long long>(static_cast<long long>(a));
+                const unsigned txbit = (ref >> (BPS - 1 - b)) & 1u;
+                sign_err += (txbit != (l[b] < 0.0f ? 1u : 0u));
+            }
+        }
+    }
+    if (counters) {
+        bit_err = wave_sum(bit_err); sym_err = wave_sum(sym_err); abs_q = wave_sum(abs_q); sign_err = wave_sum(sign_err); n_done = wave_sum(n_done);
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&counters[0], bit_err);
+            atomicAdd(&counters[1], n_done * BPS);
+            atomicAdd(&counters[2], sym_err);
+            atomicAdd(&counters[3], n_done);
+            atomicAdd(&counters[5], abs_q);
+            atomicAdd(&counters[6], sign_err);
+        }
+    }
+}
+
+__global__ void add_counter_kernel(unsigned long long* counters, int slot, unsigned long long v) { atomicAdd(&counters[slot], v); }
+
+template <typename T> T norm_in(int mod) { return T(1) / std::sqrt(static_cast<T>(grid_energy(mod))); }
+template <typename T> T inorm_in(int mod) { return std::sqrt(static_cast<T>(grid_energy(mod))); }
+
+} // namespace
+
+int to_constl_dev(sdr_ctx* ctx, bool is_double, int mod, const uint8_t* d_bytes, size_t n_sym, void* d_out)
+{
+    if (!valid_mod(mod)) return fail(SDR_ERR_INVALID, "unknown modulation %d", mod);
+    if (n_sym == 0) return SDR_OK;
+    if (!d_bytes || !d_out) return fail(SDR_ERR_INVALID, "null device pointer");
+    const unsigned grid = grid_for(ctx, n_sym);
+    dispatch_mod(mod, [&]<int MI, int MQ>() {
+        if (is_double)
+            hipLaunchKernelGGL((to_constl_kernel<double, MI, MQ>), dim3(grid), dim3(kThreads), 0, ctx->stream, d_bytes, n_sym, norm_in<double>(mod), static_cast<double*>(d_out));
+        else
+            hipLaunchKernelGGL((to_constl_kernel<float, MI, MQ>), dim3(grid), dim3(kThreads), 0, ctx->stream, d_bytes, n_sym, norm_in<float>(mod), static_cast<float*>(d_out));
+    });
+    SDR_HIP(hipGetLastError());
+    return SDR_OK;
+}
+
+static int launch_nearest(sdr_ctx* ctx, bool is_double, int mod, const void* d_sym, size_t n_sym, uint16_t* d_index)
+{
+    const unsigned grid = grid_for(ctx, n_sym);
+    dispatch_mod(mod, [&]<int MI, int MQ>() {
+        if (is_double)
+            hipLaunchKernelGGL((nearest_kernel<double, MI, MQ>), dim3(grid), dim3(kThreads), 0, ctx->stream, static_cast<const double*>(d_sym), n_sym, inorm_in<double>(mod), d_index);
+        else
+            hipLaunchKernelGGL((nearest_kernel<float, MI, MQ>), dim3(grid), dim3(kThreads), 0, ctx->stream, static_cast<const float*>(d_sym), n_sym, inorm_in<float>(mod), d_index);
+    });
+    SDR_HIP(hipGetLastError());
+    return SDR_OK;
+}
+
+int nearest_dev(sdr_ctx* ctx, int mod, const void* d_sym, size_t n_sym, uint16_t* d_index)
+{
+    if (!valid_mod(mod)) return fail(SDR_ERR_INVALID, "unknown modulation %d", mod);
+    if (n_sym == 0) return SDR_OK;
+    if (!d_sym || !d_index) return fail(SDR_ERR_INVALID, "null device pointer");
+    return launch_nearest(ctx, false, mod, d_sym, n_sym, d_index);
+}
+
+int from_constl_dev(sdr_ctx* ctx, bool is_double, int mod, const void* d_sym, size_t n_sym, uint8_t* d_bytes)
+{
+    if (!valid_mod(mod)) return fail(SDR_ERR_INVALID, "unknown modulation %d", mod);
+    const size_t n_bytes = (n_sym * static_cast<size_t>(mod)) / 8;
+    if (n_bytes == 0) return SDR_OK;
+    if (!d_sym || !d_bytes) return fail(SDR_ERR_INVALID, "null device pointer");
+    void* idx = nullptr;
+    SDR_TRY(get_staging(ctx, 1, n_sym * sizeof(uint16_t), &idx));
+    SDR_TRY(launch_nearest(ctx, is_double, mod, d_sym, n_sym, static_cast<uint16_t*>(idx)));
+    hipLaunchKernelGGL(pack_kernel, dim3(grid_for(ctx, n_bytes)), dim3(kThreads), 0, ctx->stream, static_cast<const uint16_t*>(idx), n_sym, mod, n_bytes, d_bytes);
+    SDR_HIP(hipGetLastError());
+    return SDR_OK;
+}
+
+int soft_demap_dev(sdr_ctx* ctx, int mod, const void* d_sym, size_t n_sym, const float* d_weight, float weight0, float* d_llr)
+{
+    if (!valid_mod(mod)) return fail(SDR_ERR_INVALID, "unknown modulation %d", mod);
+    if (n_sym == 0) return SDR_OK;
+    if (!d_sym || !d_llr) return fail(SDR_ERR_INVALID, "null device pointer");
+    const unsigned grid = grid_for(ctx, n_sym);
+    dispatch_mod(mod, [&]<int MI, int MQ>() {
+        hipLaunchKernelGGL((soft_demap_kernel<MI, MQ>), dim3(grid), dim3(kThreads), 0, ctx->stream, static_cast<const float*>(d_sym), n_sym, inorm_in<float>(mod), d_weight, weight0, d_llr);
+    });
+    SDR_HIP(hipGetLastError());
+    return SDR_OK;
+}
+
+int zf_taps_dev(sdr_ctx* ctx, int mod, const void* d_chan, size_t n, float inv_n0, void* d_taps, float* d_weight)
+{
+    if (!valid_mod(mod)) return fail(SDR_ERR_INVALID, "unknown modulation %d", mod);
+    if (n == 0) return SDR_OK;
+    if (!d_chan || !d_taps || !d_weight) return fail(SDR_ERR_INVALID, "null device pointer");
+    const float nrm = norm_in<float>(mod);
+    hipLaunchKernelGGL(zf_taps_kernel, dim3(grid_for(ctx, n)), dim3(kThreads), 0, ctx->stream, static_cast<const float2*>(d_chan), n, nrm * nrm, inv_n0,
+                       static_cast<float2*>(d_taps), d_weight);
+    SDR_HIP(hipGetLastError());
+    return SDR_OK;
+}
+
+int demap_after_fft(sdr_ctx* ctx, const sdr_demod_args& a, const void* d_fft)
+{
+    const size_t total = size_t(a.n_sym) * a.n_fft;
+    if (total == 0) return SDR_OK;
+    const bool want_counters = a.d_counters && a.d_ref_hard;
+    const bool want_index = a.d_hard != nullptr;
+    if (!a.d_llr && !want_index && !want_counters) return SDR_OK;
+    void* idx = nullptr;
+    if (want_index) SDR_TRY(get_staging(ctx, 1, total * sizeof(uint16_t), &idx));
+    const unsigned grid = grid_for(ctx, total);
+    const int mod = static_cast<int>(a.mod);
+    dispatch_mod(mod, [&]<int MI, int MQ>() {
+        hipLaunchKernelGGL((demap_fft_kernel<MI, MQ>), dim3(grid), dim3(kThreads), 0, ctx->stream, static_cast<const float2*>(d_fft), a.n_fft, a.n_sym,
+                           a.sym_per_set, static_cast<const float2*>(a.d_eq), a.d_llr_weight, a.llr_weight0, inorm_in<float>(mod), a.d_llr,
+                           static_cast<uint16_t*>(idx), a.d_ref_hard, want_counters ? reinterpret_cast<unsigned long long*>(a.d_counters) : nullptr);
+    });
+    SDR_HIP(hipGetLastError());
+    if (want_counters) {
+        hipLaunchKernelGGL(add_counter_kernel, dim3(1), dim3(1), 0, ctx->stream, reinterpret_cast<unsigned long long*>(a.d_counters), 4, static_cast<unsigned long long>(a.n_sym));
+        SDR_HIP(hipGetLastError());
+    }
+    if (want_index) {
+        const size_t n_bytes = (total * a.mod) / 8;
+        if (n_bytes) {
+            hipLaunchKernelGGL(pack_kernel, dim3(grid_for(ctx, n_bytes)), dim3(kThreads), 0, ctx->stream, static_cast<const uint16_t*>(idx), total, mod, n_bytes, a.d_hard);
+            SDR_HIP(hipGetLastError());
+        }
+    }
+    return SDR_OK;
+}
+
+} // namespace sdr

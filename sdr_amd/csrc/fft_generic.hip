@@ -1,0 +1,210 @@
+// fft_generic.hip -- any-size, fp32 or fp64, batched radix-2 DIT FFT that evaluates the
+// reference's network literally (lib/inc/fft.hpp:87-155): bit-reversal, then log2(n) stages of
+// butterflies t = odd*w (four products), a' = even+t, b' = even-t, with w read from the table
+// built by the reference's own recurrence (context.hip).  Compiled with -ffp-contract=off, so
+// the result is the same IEEE operation DAG as the reference.
+//
+// Two forms:
+//   * LDS form: one workgroup per sequence, the whole sequence resident in LDS (up to 128 KiB:
+//     n <= 16384 c32 / 8192 c64), one barrier per stage.  HBM traffic = one read + one write.
+//   * global form for longer sequences: one launch per stage over HBM.
+// The tuned fp32 OFDM sizes (64..4096) never come here from the fused receive path; this is
+// the generic engine behind fft::fft2/ifft2 and ofdm::rx/tx of the drop-in headers.
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace sdr {
+
+template <typename T> struct Vec2;
+template <> struct Vec2<float> { using type = float2; };
+template <> struct Vec2<double> { using type = double2; };
+
+template <typename T>
+struct FftGeom {
+    size_t in_stride;     // elements between consecutive sequences on input
+    size_t in_offset;     // elements to skip at the start of each input sequence (CP removal)
+    size_t out_stride;
+    size_t out_offset;    // elements left free at the start of each output sequence (CP slot)
+    size_t cp_fill;       // tx: number of CP samples to copy from the tail (<= n)
+    size_t n_seq;
+    T divisor;            // inverse: divide every element by this (0 = no scaling)
+};
+
+template <typename T>
+__device__ inline void butterfly(typename Vec2<T>::type& even, typename Vec2<T>::type& odd, typename Vec2<T>::type w)
+{
+    const T tr = odd.x * w.x - odd.y * w.y;
+    const T ti = odd.x * w.y + odd.y * w.x;
+    const T ar = even.x + tr, ai = even.y + ti;
+    const T br = even.x - tr, bi = even.y - ti;
+    even.x = ar; even.y = ai;
+    odd.x = br; odd.y = bi;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) fft_lds_kernel(const typename Vec2<T>::type* __restrict__ in,
+                                                      typename Vec2<T>::type* __restrict__ out,
+                                                      const typename Vec2<T>::type* __restrict__ tw,
+                                                      unsigned log2n, FftGeom<T> g)
+{
+    using V = typename Vec2<T>::type;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    V* buf = reinterpret_cast<V*>(lds_raw);
+    const unsigned n = 1u << log2n;
+    const unsigned tid = threadIdx.x;
+    for (size_t seq = blockIdx.x; seq < g.n_seq; seq += gridDim.x) {
+        const V* src = in + seq * g.in_stride + g.in_offset;
+        for (unsigned i = tid; i < n; i += blockDim.x) {
+            const unsigned r = log2n ? (__brev(i) >> (32u - log2n)) : 0u;
+            buf[r] = src[i];
+        }
+        for (unsigned c = 0; c < log2n; ++c) {
+            __syncthreads();
+            const unsigned half = 1u << c;
+            for (unsigned b = tid; b < (n >> 1); b += blockDim.x) {
+                const unsigned j = b & (half - 1u);
+                const unsigned pos = ((b >> c) << (c + 1u)) | j;
+                V e = buf[pos], o = buf[pos + half];
+                butterfly<T>(e, o, tw[half - 1u + j]);
+                buf[pos] = e;
+                buf[pos + half] = o;
+            }
+        }
+        __syncthreads();
+        V* dst = out + seq * g.out_stride;
+        for (unsigned i = tid; i < n; i += blockDim.x) {
+            V v = buf[i];
+            if (g.divisor != T(0)) { v.x /= g.divisor; v.y /= g.divisor; }
+            dst[g.out_offset + i] = v;
+            if (i + g.cp_fill >= n) dst[i + g.cp_fill - n] = v;   // cyclic prefix = copy of the tail
+        }
+        __syncthreads();
+    }
+}
+
+// ---- global-memory form -----------------------------------------------------------------
+template <typename T>
+__global__ void bitrev_gather_kernel(const typename Vec2<T>::type* __restrict__ in, typename Vec2<T>::type* __restrict__ out,
+                                     unsigned log2n, FftGeom<T> g)
+{
+    const size_t n = size_t(1) << log2n;
+    const size_t total = n * g.n_seq;
+    for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
+        const size_t seq = idx >> log2n;
+        const size_t i = idx & (n - 1);
+        const size_t r = log2n ? (__brevll(i) >> (64u - log2n)) : 0;
+        out[seq * g.out_stride + g.out_offset + r] = in[seq * g.in_stride + g.in_offset + i];
+    }
+}
+
+template <typename T>
+__global__ void stage_global_kernel(typename Vec2<T>::type* __restrict__ data, const typename Vec2<T>::type* __restrict__ tw,
+                                    unsigned log2n, unsigned c, FftGeom<T> g)
+{
+    using V = typename Vec2<T>::type;
+    const size_t half_n = (size_t(1) << log2n) >> 1;
+    const size_t total = half_n * g.n_seq;
+    const size_t half = size_t(1) << c;
+    for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
+        const size_t seq = idx / half_n;
+        const size_t b = idx - seq * half_n;
+        const size_t j = b & (half - 1);
+        const size_t pos = ((b >> c) << (c + 1)) | j;
+        V* base = data + seq * g.out_stride + g.out_offset;
+        V e = base[pos], o = base[pos + half];
+        butterfly<T>(e, o, tw[half - 1 + j]);
+        base[pos] = e;
+        base[pos + half] = o;
+    }
+}
+
+template <typename T>
+__global__ void finish_global_kernel(typename Vec2<T>::type* __restrict__ data, unsigned log2n, FftGeom<T> g)
+{
+    using V = typename Vec2<T>::type;
+    const size_t n = size_t(1) << log2n;
+    const size_t total = n * g.n_seq;
+    for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
+        const size_t seq = idx >> log2n;
+        const size_t i = idx & (n - 1);
+        V* base = data + seq * g.out_stride;
+        V v = base[g.out_offset + i];
+        if (g.divisor != T(0)) { v.x /= g.divisor; v.y /= g.divisor; base[g.out_offset + i] = v; }
+        if (i + g.cp_fill >= n) base[i + g.cp_fill - n] = v;
+    }
+}
+
+template <typename T>
+static int run_fft(sdr_ctx* ctx, const void* d_in, void* d_out, size_t n, bool inverse,
+                   size_t in_stride, size_t in_offset, size_t out_stride, size_t out_offset, size_t cp_fill, size_t n_seq)
+{
+    using V = typename Vec2<T>::type;
+    if (n_seq == 0 || n == 0) return SDR_OK;
+    if (!is_pow2(n)) return fail(SDR_ERR_NOT_POW2, "%s", kPow2Message);
+    if (!d_in || !d_out) return fail(SDR_ERR_INVALID, "null device pointer");
+    if (n > (size_t(1) << 30)) return fail(SDR_ERR_UNSUPPORTED, "sequence length %zu too large", n);
+    const unsigned log2n = ilog2(n);
+    const void* tw = nullptr;
+    if (n >= 2) SDR_TRY(get_twiddles(ctx, n, inverse, sizeof(T) == 8, &tw));
+    FftGeom<T> g;
+    g.in_stride = in_stride; g.in_offset = in_offset;
+    g.out_stride = out_stride; g.out_offset = out_offset;
+    g.cp_fill = cp_fill; g.n_seq = n_seq;
+    g.divisor = inverse ? static_cast<T>(static_cast<ptrdiff_t>(n)) : T(0);
+    const size_t lds_bytes = n * sizeof(V);
+    const size_t lds_cap = ctx->lds_max < size_t(128) * 1024 ? ctx->lds_max : size_t(128) * 1024;
+    const bool aliased = (d_in == d_out);
+    if (lds_bytes <= lds_cap) {
+        auto kern = fft_lds_kernel<T>;
+        if (lds_bytes > 48 * 1024)
+            SDR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes)));
+        size_t blocks = n_seq;
+        const size_t cap = size_t(ctx->num_cu) * 16;
+        if (blocks > cap) blocks = cap;
+        unsigned threads = 256;
+        if (n / 2 < threads) threads = n / 2 < 64 ? 64 : static_cast<unsigned>(n / 2);
+        hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(threads), lds_bytes, ctx->stream,
+                           static_cast<const V*>(d_in), static_cast<V*>(d_out), static_cast<const V*>(tw), log2n, g);
+        SDR_HIP(hipGetLastError());
+        return SDR_OK;
+    }
+    // global form; in-place needs a scratch copy for the bit-reversal gather
+    const V* src = static_cast<const V*>(d_in);
+    FftGeom<T> gg = g;
+    if (aliased) {
+        void* tmp = nullptr;
+        SDR_TRY(get_staging(ctx, 2, n * n_seq * sizeof(V), &tmp));
+        // compact copy of the inputs
+        for (size_t s = 0; s < n_seq; ++s)
+            SDR_HIP(hipMemcpyAsync(static_cast<V*>(tmp) + s * n, src + s * in_stride + in_offset, n * sizeof(V), hipMemcpyDeviceToDevice, ctx->stream));
+        src = static_cast<const V*>(tmp);
+        gg.in_stride = n; gg.in_offset = 0;
+    }
+    const unsigned threads = 256;
+    const unsigned blocks = static_cast<unsigned>(ctx->num_cu) * 8;
+    hipLaunchKernelGGL(bitrev_gather_kernel<T>, dim3(blocks), dim3(threads), 0, ctx->stream, src, static_cast<V*>(d_out), log2n, gg);
+    SDR_HIP(hipGetLastError());
+    for (unsigned c = 0; c < log2n; ++c) {
+        hipLaunchKernelGGL(stage_global_kernel<T>, dim3(blocks), dim3(threads), 0, ctx->stream, static_cast<V*>(d_out), static_cast<const V*>(tw), log2n, c, gg);
+        SDR_HIP(hipGetLastError());
+    }
+    if (inverse || cp_fill) {
+        hipLaunchKernelGGL(finish_global_kernel<T>, dim3(blocks), dim3(threads), 0, ctx->stream, static_cast<V*>(d_out), log2n, gg);
+        SDR_HIP(hipGetLastError());
+    }
+    return SDR_OK;
+}
+
+int fft_generic_f32(sdr_ctx* ctx, const void* d_in, void* d_out, size_t n, bool inverse,
+                    size_t in_stride, size_t in_offset, size_t out_stride, size_t out_offset, size_t cp_fill, size_t n_seq)
+{
+    return run_fft<float>(ctx, d_in, d_out, n, inverse, in_stride, in_offset, out_stride, out_offset, cp_fill, n_seq);
+}
+
+int fft_generic_f64(sdr_ctx* ctx, const void* d_in, void* d_out, size_t n, bool inverse,
+                    size_t in_stride, size_t in_offset, size_t out_stride, size_t out_offset, size_t cp_fill, size_t n_seq)
+{
+    return run_fft<double>(ctx, d_in, d_out, n, inverse, in_stride, in_offset, out_stride, out_offset, cp_fill, n_seq);
+}
+
+} // namespace sdr

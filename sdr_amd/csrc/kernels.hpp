@@ -1,0 +1,32 @@
+// kernels.hpp -- internal entry points of the HIP translation units (not part of the C ABI).
+#pragma once
+
+#include "common.hpp"
+
+namespace sdr {
+
+// fft_generic.hip: the reference network for any power-of-two length, fp32/fp64.
+int fft_generic_f32(sdr_ctx* ctx, const void* d_in, void* d_out, size_t n, bool inverse,
+                    size_t in_stride, size_t in_offset, size_t out_stride, size_t out_offset, size_t cp_fill, size_t n_seq);
+int fft_generic_f64(sdr_ctx* ctx, const void* d_in, void* d_out, size_t n, bool inverse,
+                    size_t in_stride, size_t in_offset, size_t out_stride, size_t out_offset, size_t cp_fill, size_t n_seq);
+
+// demap.hip: element-wise constellation kernels.
+int to_constl_dev(sdr_ctx* ctx, bool is_double, int mod, const uint8_t* d_bytes, size_t n_sym, void* d_out);
+int from_constl_dev(sdr_ctx* ctx, bool is_double, int mod, const void* d_sym, size_t n_sym, uint8_t* d_bytes);
+int nearest_dev(sdr_ctx* ctx, int mod, const void* d_sym, size_t n_sym, uint16_t* d_index);
+int soft_demap_dev(sdr_ctx* ctx, int mod, const void* d_sym, size_t n_sym, const float* d_weight, float weight0, float* d_llr);
+int zf_taps_dev(sdr_ctx* ctx, int mod, const void* d_chan, size_t n, float inv_n0, void* d_taps, float* d_weight);
+// equalise + LLR + hard + counters on FFT outputs already in memory (generic sizes of the fused path)
+int demap_after_fft(sdr_ctx* ctx, const sdr_demod_args& a, const void* d_fft);
+
+// rx_fused.hip: the tuned fused receive kernel (fp32, n_fft 64..4096).
+bool rx_fused_supported(uint32_t n_fft, uint32_t mod);
+int rx_fused_launch(sdr_ctx* ctx, const sdr_demod_args& a);
+int rx_fft_only_launch(sdr_ctx* ctx, const void* d_in, uint32_t n_fft, uint32_t cp, uint64_t n_sym, void* d_out);
+
+// link.hip: frame generator, AWGN, Monte-Carlo link.
+int link_generate(sdr_ctx* ctx, const sdr_link_args& a);
+int link_ber(sdr_ctx* ctx, const sdr_link_args& a);
+
+} // namespace sdr

@@ -1,0 +1,172 @@
+// link.hip -- device frame generator, AWGN channel and Monte-Carlo link (no reference
+// counterpart; modelled on the end-to-end loop app/QFDemoWindow.cpp:201-224 with a channel
+// inserted between ofdm::tx and ofdm::rx).
+//
+// generate:  Philox index -> to_constl (modulation.hpp:78-94) -> optional x H_k -> ofdm::tx
+//            (ofdm.hpp:13-24: IFFT with the reference network, /N, CP) -> + Gaussian noise.
+// ber:       generate -> fused receive path -> counters, in bounded chunks of device scratch.
+#include "common.hpp"
+#include "kernels.hpp"
+#include "qam.hpp"
+#include "rng.hpp"
+
+#include <cmath>
+
+namespace sdr {
+
+namespace {
+
+constexpr unsigned kThreads = 256;
+
+inline unsigned grid_for(sdr_ctx* ctx, size_t work)
+{
+    size_t blocks = (work + kThreads - 1) / kThreads;
+    const size_t cap = size_t(ctx->num_cu) * 16;
+    if (blocks > cap) blocks = cap;
+    if (blocks == 0) blocks = 1;
+    return static_cast<unsigned>(blocks);
+}
+
+template <int MI, int MQ>
+__global__ void gen_freq_kernel(uint32_t n_fft, uint64_t seed, uint64_t g0, uint64_t n_sym, uint32_t sym_per_set, float norm,
+                                const float2* __restrict__ chan, float2* __restrict__ freq, uint16_t* __restrict__ index)
+{
+    constexpr int BPS = MI + MQ;
+    const size_t total = size_t(n_sym) * n_fft;
+    const uint64_t first_set = sym_per_set ? g0 / sym_per_set : 0;
+    for (size_t e = blockIdx.x * size_t(blockDim.x) + threadIdx.x; e < total; e += size_t(gridDim.x) * blockDim.x) {
+        const size_t s = e / n_fft;
+        const uint32_t k = static_cast<uint32_t>(e - s * n_fft);
+        const uint64_t g = g0 + s;
+        const unsigned idx = tx_index(seed, g, k, n_fft, BPS);
+        const unsigned gi = idx >> MQ, gq = idx & ((1u << MQ) - 1u);
+        float li = 0.0f, lq = 0.0f;
+#pragma unroll
+        for (unsigned c = 0; c < (1u << MI); ++c) li = (c == gi) ? axis_level<float, MI>(c) : li;
+#pragma unroll
+        for (unsigned c = 0; c < (1u << MQ); ++c) lq = (c == gq) ? axis_level<float, MQ>(c) : lq;
+        float xr = li * norm, xi = lq * norm;
+        if (chan) {
+            const size_t set = sym_per_set ? static_cast<size_t>(g / sym_per_set - first_set) : 0;
+            const float2 h = chan[set * n_fft + k];
+            const float tr = xr * h.x - xi * h.y;
+            const float ti = xr * h.y + xi * h.x;
+            xr = tr; xi = ti;
+        }
+        freq[e] = make_float2(xr, xi);
+        if (index) index[e] = static_cast<uint16_t>(idx);
+    }
+}
+
+__global__ void add_noise_kernel(uint32_t n_fft, uint32_t cp, uint64_t seed, uint64_t g0, uint64_t n_sym, float sigma, float2* __restrict__ rx)
+{
+    const uint32_t len = n_fft + cp;
+    const size_t total = size_t(n_sym) * len;
+    for (size_t e = blockIdx.x * size_t(blockDim.x) + threadIdx.x; e < total; e += size_t(gridDim.x) * blockDim.x) {
+        const size_t s = e / len;
+        const uint32_t i = static_cast<uint32_t>(e - s * len);
+        const uint64_t g = g0 + s;
+        const float2 nz = (i < cp) ? cp_noise(seed, g, i, sigma) : payload_noise(seed, g, i - cp, n_fft, sigma);
+        float2 v = rx[e];
+        v.x = v.x + nz.x;
+        v.y = v.y + nz.y;
+        rx[e] = v;
+    }
+}
+
+// one thread per output byte (same packing rule as demap.hip)
+__global__ void pack_index_kernel(const uint16_t* __restrict__ index, size_t n_sym, int bps, size_t n_bytes, uint8_t* __restrict__ out)
+{
+    for (size_t b = blockIdx.x * size_t(blockDim.x) + threadIdx.x; b < n_bytes; b += size_t(gridDim.x) * blockDim.x) {
+        unsigned v = 0;
+        for (int i = 0; i < 8; ++i) {
+            const size_t pos = b * 8 + i;
+            const size_t k = pos / bps;
+            const int within = static_cast<int>(pos - k * bps);
+            const unsigned bit = (k < n_sym) ? ((index[k] >> (bps - 1 - within)) & 1u) : 0u;
+            v = (v << 1) | bit;
+        }
+        out[b] = static_cast<uint8_t>(v);
+    }
+}
+
+int check_link(const sdr_link_args& a)
+{
+    if (a.struct_size != sizeof(sdr_link_args)) return fail(SDR_ERR_INVALID, "sdr_link_args.struct_size %u != %zu", a.struct_size, sizeof(sdr_link_args));
+    if (!valid_mod(static_cast<int>(a.mod))) return fail(SDR_ERR_INVALID, "unknown modulation %u", a.mod);
+    if (a.n_fft == 0 || !is_pow2(a.n_fft)) return fail(SDR_ERR_NOT_POW2, "%s", kPow2Message);
+    if (a.cp > a.n_fft) return fail(SDR_ERR_INVALID, "cyclic prefix %u longer than the FFT %u", a.cp, a.n_fft);
+    if ((size_t(a.n_fft) * a.mod) % 8 != 0) return fail(SDR_ERR_UNSUPPORTED, "n_fft*mod must be a multiple of 8 bits");
+    return SDR_OK;
+}
+
+} // namespace
+
+int link_generate(sdr_ctx* ctx, const sdr_link_args& a)
+{
+    SDR_TRY(check_link(a));
+    if (a.n_sym == 0) return SDR_OK;
+    if (!a.d_rx) return fail(SDR_ERR_INVALID, "null d_rx");
+    const size_t total = size_t(a.n_sym) * a.n_fft;
+    void* freq = nullptr;
+    void* idx = nullptr;
+    SDR_TRY(get_staging(ctx, 0, total * sizeof(float2), &freq));
+    if (a.d_tx_bits) SDR_TRY(get_staging(ctx, 1, total * sizeof(uint16_t), &idx));
+    const int mod = static_cast<int>(a.mod);
+    const float norm = 1.0f / std::sqrt(static_cast<float>(grid_energy(mod)));
+    const unsigned grid = grid_for(ctx, total);
+    dispatch_mod(mod, [&]<int MI, int MQ>() {
+        hipLaunchKernelGGL((gen_freq_kernel<MI, MQ>), dim3(grid), dim3(kThreads), 0, ctx->stream, a.n_fft, a.seed, a.first_symbol, a.n_sym, a.sym_per_set, norm,
+                           static_cast<const float2*>(a.d_chan), static_cast<float2*>(freq), static_cast<uint16_t*>(idx));
+    });
+    SDR_HIP(hipGetLastError());
+    SDR_TRY(fft_generic_f32(ctx, freq, a.d_rx, a.n_fft, true, a.n_fft, 0, size_t(a.n_fft) + a.cp, a.cp, a.cp, a.n_sym));
+    const size_t samples = size_t(a.n_sym) * (size_t(a.n_fft) + a.cp);
+    hipLaunchKernelGGL(add_noise_kernel, dim3(grid_for(ctx, samples)), dim3(kThreads), 0, ctx->stream, a.n_fft, a.cp, a.seed, a.first_symbol, a.n_sym, a.sigma,
+                       static_cast<float2*>(a.d_rx));
+    SDR_HIP(hipGetLastError());
+    if (a.d_tx_bits) {
+        const size_t n_bytes = total * a.mod / 8;
+        hipLaunchKernelGGL(pack_index_kernel, dim3(grid_for(ctx, n_bytes)), dim3(kThreads), 0, ctx->stream, static_cast<const uint16_t*>(idx), total, mod, n_bytes, a.d_tx_bits);
+        SDR_HIP(hipGetLastError());
+    }
+    return SDR_OK;
+}
+
+// Monte-Carlo link: symbols are produced and consumed chunk by chunk in device scratch; only
+// the eight counters are outputs.  (Tuned sizes use the fully fused kernel in rx_fused.hip.)
+int link_ber(sdr_ctx* ctx, const sdr_link_args& a)
+{
+    SDR_TRY(check_link(a));
+    if (!a.d_counters) return fail(SDR_ERR_INVALID, "null d_counters");
+    if (a.n_sym == 0) return SDR_OK;
+    const size_t sym_bytes = (size_t(a.n_fft) + a.cp) * sizeof(float2);
+    size_t chunk = (size_t(256) << 20) / sym_bytes;
+    if (chunk == 0) chunk = 1;
+    if (chunk > a.n_sym) chunk = a.n_sym;
+    void* rx = nullptr;
+    void* bits = nullptr;
+    SDR_TRY(get_staging(ctx, 3, chunk * sym_bytes, &rx));
+    SDR_TRY(get_staging(ctx, 4, chunk * a.n_fft * a.mod / 8, &bits));
+    for (uint64_t done = 0; done < a.n_sym; done += chunk) {
+        const uint64_t now = (a.n_sym - done < chunk) ? a.n_sym - done : chunk;
+        sdr_link_args g = a;
+        g.first_symbol = a.first_symbol + done;
+        g.n_sym = now;
+        g.d_chan = nullptr;
+        g.d_rx = rx;
+        g.d_tx_bits = static_cast<uint8_t*>(bits);
+        SDR_TRY(link_generate(ctx, g));
+        sdr_demod_args d = {};
+        d.struct_size = sizeof(sdr_demod_args);
+        d.n_fft = a.n_fft; d.cp = a.cp; d.mod = a.mod; d.n_sym = now;
+        d.sym_per_set = 0; d.llr_weight0 = a.llr_weight0;
+        d.d_rx = rx;
+        d.d_ref_hard = static_cast<const uint8_t*>(bits);
+        d.d_counters = a.d_counters;
+        SDR_TRY(sdr_ofdm_demod_c32(ctx, &d));
+    }
+    return SDR_OK;
+}
+
+} // namespace sdr

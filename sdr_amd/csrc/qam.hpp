@@ -1,0 +1,149 @@
+// qam.hpp -- device-side square-QAM arithmetic shared by the demapping kernels.
+//
+// Constellation rule (reference 16-QAM: lib/inc/modulation.hpp:15-47; other orders extend it):
+// index bits MSB first, high MI bits -> I axis, low MQ bits -> Q axis, per-axis Gray code,
+// level = 2*gray_decode(g) - (2^m - 1).  BPSK is MI = 1, MQ = 0 (Q level 0).
+//
+// nearest() (lib/inc/modulation.hpp:49-67) scans all 2^(MI+MQ) points in ascending index with
+// d2 = dx*dx + dy*dy and a strict '<' from numeric_limits::max().  Here the same decision is
+// obtained from the per-axis squared distances: rounding is monotonic, so the scan's minimum is
+// m = fl(min_a DX[a] + min_b DY[b]), and the first index that attains it is the smallest I code
+// gi with fl(DX[gi] + min_b DY[b]) == m followed by the smallest Q code gq with
+// fl(DX[gi] + DY[gq]) == m.  Ties created by rounding (far-away points) therefore resolve to the
+// lowest index exactly like the scan.  NaN / overflow (m not < max) leave index 0, also like it.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace sdr {
+
+template <typename T> struct FltMax;
+template <> struct FltMax<float> { static __device__ __host__ constexpr float value() { return 3.402823466e+38f; } };
+template <> struct FltMax<double> { static __device__ __host__ constexpr double value() { return 1.7976931348623157e+308; } };
+
+__device__ __host__ constexpr unsigned gray_to_binary(unsigned g)
+{
+    return g ^ (g >> 1) ^ (g >> 2) ^ (g >> 3) ^ (g >> 4);   // enough for 5 bits per axis
+}
+
+template <typename T, int M>
+__device__ __host__ constexpr T axis_level(unsigned g)
+{
+    return M == 0 ? T(0) : T(2 * static_cast<int>(gray_to_binary(g)) - ((1 << M) - 1));
+}
+
+template <typename T> __device__ inline T min_of(T a, T b) { return a < b ? a : b; }
+template <> __device__ inline float min_of<float>(float a, float b) { return fminf(a, b); }
+template <> __device__ inline double min_of<double>(double a, double b) { return fmin(a, b); }
+
+// squared distances from coordinate v to every level of an axis with M bits
+template <typename T, int M>
+__device__ inline void axis_distances(T v, T (&d)[1 << M])
+{
+#pragma unroll
+    for (unsigned g = 0; g < (1u << M); ++g) {
+        const T diff = v - axis_level<T, M>(g);
+        d[g] = diff * diff;
+    }
+}
+
+template <typename T, int N>
+__device__ inline T array_min(const T (&d)[N])
+{
+    T m = d[0];
+#pragma unroll
+    for (int i = 1; i < N; ++i) m = min_of<T>(m, d[i]);
+    return m;
+}
+
+// Hard decision on the scaled point (ur, ui) = point * inorm, given the axis distances.
+template <typename T, int MI, int MQ>
+__device__ inline unsigned nearest_from_distances(const T (&dx)[1 << MI], const T (&dy)[1 << MQ])
+{
+    const T dxm = array_min<T, (1 << MI)>(dx);
+    const T dym = array_min<T, (1 << MQ)>(dy);
+    const T m = dxm + dym;
+    unsigned gi = 0;
+    T dxi = dx[0];
+    bool hit = false;
+#pragma unroll
+    for (int g = (1 << MI) - 1; g >= 0; --g) {
+        const bool eq = (dx[g] + dym) == m;
+        gi = eq ? static_cast<unsigned>(g) : gi;
+        dxi = eq ? dx[g] : dxi;
+        hit = hit || eq;
+    }
+    unsigned gq = 0;
+#pragma unroll
+    for (int g = (1 << MQ) - 1; g >= 0; --g) {
+        const bool eq = (dxi + dy[g]) == m;
+        gq = eq ? static_cast<unsigned>(g) : gq;
+    }
+    const unsigned idx = (gi << MQ) | gq;
+    return (hit && m < FltMax<T>::value()) ? idx : 0u;
+}
+
+// Max-log LLRs of one axis: for axis bit b (MSB first), min over levels with Gray bit 1 minus
+// min over levels with Gray bit 0, times w.  out[0..M).
+template <typename T, int M>
+__device__ inline void axis_llr(const T (&d)[1 << M], T w, T* out)
+{
+#pragma unroll
+    for (int b = M - 1; b >= 0; --b) {
+        T d0 = T(0), d1 = T(0);
+        bool h0 = false, h1 = false;
+#pragma unroll
+        for (unsigned g = 0; g < (1u << M); ++g) {
+            if ((g >> b) & 1u) { d1 = h1 ? min_of<T>(d1, d[g]) : d[g]; h1 = true; }
+            else               { d0 = h0 ? min_of<T>(d0, d[g]) : d[g]; h0 = true; }
+        }
+        out[M - 1 - b] = (d1 - d0) * w;
+    }
+}
+
+// Everything for one subcarrier: scaled coordinates -> LLRs (MI+MQ values) and index.
+template <typename T, int MI, int MQ, bool WANT_LLR, bool WANT_IDX>
+__device__ inline unsigned demap_point(T re, T im, T inorm, T w, T* llr)
+{
+    const T ur = re * inorm;
+    const T ui = im * inorm;
+    T dx[1 << MI];
+    T dy[1 << MQ];
+    axis_distances<T, MI>(ur, dx);
+    axis_distances<T, MQ>(ui, dy);
+    if (WANT_LLR) {
+        axis_llr<T, MI>(dx, w, llr);
+        if (MQ > 0) axis_llr<T, MQ>(dy, w, llr + MI);
+    }
+    unsigned idx = 0;
+    if (WANT_IDX) idx = nearest_from_distances<T, MI, MQ>(dx, dy);
+    return idx;
+}
+
+// Runtime-modulation dispatch helper: calls f.template operator()<MI,MQ>() for the given bps.
+template <typename F>
+__device__ __host__ inline bool dispatch_mod(int bps, F&& f)
+{
+    switch (bps) {
+        case 1: f.template operator()<1, 0>(); return true;
+        case 2: f.template operator()<1, 1>(); return true;
+        case 4: f.template operator()<2, 2>(); return true;
+        case 6: f.template operator()<3, 3>(); return true;
+        case 8: f.template operator()<4, 4>(); return true;
+        case 10: f.template operator()<5, 5>(); return true;
+        default: return false;
+    }
+}
+
+inline bool valid_mod(int bps) { return bps == 1 || bps == 2 || bps == 4 || bps == 6 || bps == 8 || bps == 10; }
+
+// Host: Es on the integer grid, and the reference's norm / inorm taken in T
+// (lib/inc/modulation.hpp:20,23: norm = T{1}/sqrt(T{10}), inorm = sqrt(T{10})).
+inline double grid_energy(int bps)
+{
+    if (bps == 1) return 1.0;
+    const double l = static_cast<double>(1 << (bps / 2));
+    return 2.0 * (l * l - 1.0) / 3.0;
+}
+
+} // namespace sdr

@@ -1,0 +1,240 @@
+"""Host-side mirror of the reference's fft / ofdm / modulation interface on device tensors.
+
+Names and argument meaning follow the reference headers (lib/inc/fft.hpp, ofdm.hpp,
+modulation.hpp); each method calls the C ABI of libsdr_amd.so with torch tensors used only as
+device memory.  Complex tensors are torch.complex64 / complex128, contiguous, on the GPU.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import capi
+from .capi import DemodArgs, LinkArgs, check
+
+MODS = {"bpsk": 1, "qpsk": 2, "16qam": 4, "64qam": 6, "256qam": 8, "1024qam": 10}
+
+COUNTER_NAMES = ("bit_errors", "bits", "symbol_errors", "symbols", "ofdm_symbols", "llr_abs_q10", "llr_sign_errors", "reserved")
+
+
+def mod_bits(mod) -> int:
+    if isinstance(mod, str):
+        return MODS[mod.lower()]
+    return int(mod)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _need(t: torch.Tensor, dtype, name: str, numel: Optional[int] = None):
+    if not t.is_cuda:
+        raise ValueError(f"{name} must be a GPU tensor")
+    if t.dtype != dtype:
+        raise ValueError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    if numel is not None and t.numel() != numel:
+        raise ValueError(f"{name} must have {numel} elements, got {t.numel()}")
+
+
+@dataclass
+class DemodResult:
+    llr: Optional[torch.Tensor]
+    hard: Optional[torch.Tensor]
+    fft: Optional[torch.Tensor]
+
+
+class Context:
+    """One device + one stream (sdr_ctx).  Enqueues on torch's current stream of `device`."""
+
+    def __init__(self, device: int = 0):
+        self.lib = capi.load()
+        self.device = int(device)
+        if not torch.cuda.is_available():
+            raise RuntimeError("no HIP device visible; sdr_amd has no CPU fallback")
+        torch.cuda.set_device(self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        h = ctypes.c_void_p()
+        check(self.lib.sdr_create_on_stream(self.device, ctypes.c_void_p(stream), ctypes.byref(h)))
+        self._h = h
+        self.torch_device = torch.device("cuda", self.device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.sdr_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        check(self.lib.sdr_synchronize(self._h))
+
+    # ---- fft::fft2 / fft::ifft2 (lib/inc/fft.hpp:176-205), in place, batched over rows ----
+    def fft2_(self, x: torch.Tensor, inverse: bool = False) -> torch.Tensor:
+        if x.dtype not in (torch.complex64, torch.complex128):
+            raise ValueError("fft2_ needs a complex tensor")
+        _need(x, x.dtype, "x")
+        n = x.shape[-1] if x.dim() else 1
+        batch = x.numel() // n if n else 0
+        fn = self.lib.sdr_fft2_c32 if x.dtype == torch.complex64 else self.lib.sdr_fft2_c64
+        check(fn(self._h, _ptr(x), n, batch, int(inverse)))
+        return x
+
+    def ifft2_(self, x: torch.Tensor) -> torch.Tensor:
+        return self.fft2_(x, inverse=True)
+
+    # ---- ofdm::rx / ofdm::tx (lib/inc/ofdm.hpp:13-54), batched ----
+    def ofdm_rx(self, rx: torch.Tensor, n_fft: int, cp: int) -> torch.Tensor:
+        _need(rx, rx.dtype, "rx")
+        n_sym = rx.numel() // (n_fft + cp) if (n_fft + cp) else 0
+        if rx.numel() != n_sym * (n_fft + cp):
+            raise ValueError("rx length is not a multiple of n_fft+cp")
+        out = torch.empty((n_sym, n_fft), dtype=rx.dtype, device=rx.device)
+        fn = self.lib.sdr_ofdm_rx_c32 if rx.dtype == torch.complex64 else self.lib.sdr_ofdm_rx_c64
+        check(fn(self._h, _ptr(rx), n_fft, cp, n_sym, _ptr(out)))
+        return out
+
+    def ofdm_tx(self, freq: torch.Tensor, n_fft: int, cp: int) -> torch.Tensor:
+        _need(freq, freq.dtype, "freq")
+        n_sym = freq.numel() // n_fft if n_fft else 0
+        out = torch.empty((n_sym, n_fft + cp), dtype=freq.dtype, device=freq.device)
+        fn = self.lib.sdr_ofdm_tx_c32 if freq.dtype == torch.complex64 else self.lib.sdr_ofdm_tx_c64
+        check(fn(self._h, _ptr(freq), n_fft, cp, n_sym, _ptr(out)))
+        return out
+
+    # ---- modulation::to_constl / from_constl / nearest (lib/inc/modulation.hpp:49-112) ----
+    def to_constl(self, data: torch.Tensor, mod, n_sym: Optional[int] = None, dtype=torch.complex64) -> torch.Tensor:
+        bps = mod_bits(mod)
+        _need(data, torch.uint8, "data")
+        if n_sym is None:
+            n_sym = data.numel() * 8 // bps
+        out = torch.empty(n_sym, dtype=dtype, device=data.device)
+        fn = self.lib.sdr_to_constl_c32 if dtype == torch.complex64 else self.lib.sdr_to_constl_c64
+        check(fn(self._h, bps, _ptr(data), n_sym, _ptr(out)))
+        return out
+
+    def from_constl(self, sym: torch.Tensor, mod) -> torch.Tensor:
+        bps = mod_bits(mod)
+        _need(sym, sym.dtype, "sym")
+        n_sym = sym.numel()
+        out = torch.empty(n_sym * bps // 8, dtype=torch.uint8, device=sym.device)
+        fn = self.lib.sdr_from_constl_c32 if sym.dtype == torch.complex64 else self.lib.sdr_from_constl_c64
+        check(fn(self._h, bps, _ptr(sym), n_sym, _ptr(out)))
+        return out
+
+    def nearest(self, sym: torch.Tensor, mod) -> torch.Tensor:
+        bps = mod_bits(mod)
+        _need(sym, torch.complex64, "sym")
+        out = torch.empty(sym.numel(), dtype=torch.int16, device=sym.device)
+        check(self.lib.sdr_nearest_c32(self._h, bps, _ptr(sym), sym.numel(), _ptr(out)))
+        return out
+
+    def soft_demap(self, sym: torch.Tensor, mod, weight=1.0) -> torch.Tensor:
+        bps = mod_bits(mod)
+        _need(sym, torch.complex64, "sym")
+        out = torch.empty((sym.numel(), bps), dtype=torch.float32, device=sym.device)
+        wt = weight if isinstance(weight, torch.Tensor) else None
+        w0 = 0.0 if wt is not None else float(weight)
+        if wt is not None:
+            _need(wt, torch.float32, "weight", sym.numel())
+        check(self.lib.sdr_soft_demap_c32(self._h, bps, _ptr(sym), sym.numel(), _ptr(wt), w0, _ptr(out)))
+        return out
+
+    def zf_taps(self, chan: torch.Tensor, mod, inv_n0: float):
+        bps = mod_bits(mod)
+        _need(chan, torch.complex64, "chan")
+        taps = torch.empty_like(chan)
+        wgt = torch.empty(chan.shape, dtype=torch.float32, device=chan.device)
+        check(self.lib.sdr_zf_taps_c32(self._h, bps, _ptr(chan), chan.numel(), float(inv_n0), _ptr(taps), _ptr(wgt)))
+        return taps, wgt
+
+    # ---- fused receive path: CP removal -> FFT -> equalise -> LLR (+ hard bits, counters) ----
+    def demod(self, rx: torch.Tensor, n_fft: int, cp: int, mod, *, eq: Optional[torch.Tensor] = None,
+              llr_weight=1.0, sym_per_set: int = 0, want_llr: bool = True, want_hard: bool = False,
+              want_fft: bool = False, ref_hard: Optional[torch.Tensor] = None, counters: Optional[torch.Tensor] = None,
+              out_llr: Optional[torch.Tensor] = None, out_hard: Optional[torch.Tensor] = None,
+              out_fft: Optional[torch.Tensor] = None) -> DemodResult:
+        bps = mod_bits(mod)
+        _need(rx, torch.complex64, "rx")
+        n_sym = rx.numel() // (n_fft + cp)
+        if rx.numel() != n_sym * (n_fft + cp):
+            raise ValueError("rx length is not a multiple of n_fft+cp")
+        dev = rx.device
+        llr = out_llr if out_llr is not None else (torch.empty((n_sym, n_fft, bps), dtype=torch.float32, device=dev) if want_llr else None)
+        hard = out_hard if out_hard is not None else (torch.empty(n_sym * n_fft * bps // 8, dtype=torch.uint8, device=dev) if want_hard else None)
+        fft = out_fft if out_fft is not None else (torch.empty((n_sym, n_fft), dtype=torch.complex64, device=dev) if want_fft else None)
+        wt = llr_weight if isinstance(llr_weight, torch.Tensor) else None
+        a = DemodArgs()
+        a.struct_size = ctypes.sizeof(DemodArgs)
+        a.n_fft, a.cp, a.mod, a.n_sym = n_fft, cp, bps, n_sym
+        a.sym_per_set = sym_per_set
+        a.llr_weight0 = 0.0 if wt is not None else float(llr_weight)
+        a.d_rx = rx.data_ptr()
+        if eq is not None:
+            _need(eq, torch.complex64, "eq")
+            a.d_eq = eq.data_ptr()
+        if wt is not None:
+            _need(wt, torch.float32, "llr_weight")
+            a.d_llr_weight = wt.data_ptr()
+        if llr is not None:
+            _need(llr, torch.float32, "llr", n_sym * n_fft * bps)
+            a.d_llr = llr.data_ptr()
+        if hard is not None:
+            _need(hard, torch.uint8, "hard", n_sym * n_fft * bps // 8)
+            a.d_hard = hard.data_ptr()
+        if fft is not None:
+            _need(fft, torch.complex64, "fft", n_sym * n_fft)
+            a.d_fft = fft.data_ptr()
+        if ref_hard is not None:
+            _need(ref_hard, torch.uint8, "ref_hard", n_sym * n_fft * bps // 8)
+            _need(counters, torch.int64, "counters", 8)
+            a.d_ref_hard = ref_hard.data_ptr()
+            a.d_counters = counters.data_ptr()
+        check(self.lib.sdr_ofdm_demod_c32(self._h, ctypes.byref(a)))
+        return DemodResult(llr, hard, fft)
+
+    # ---- device frame generator / AWGN / Monte-Carlo link ----
+    def _link_args(self, n_fft, cp, mod, seed, first_symbol, n_sym, sigma, sym_per_set=0, llr_weight=1.0) -> LinkArgs:
+        a = LinkArgs()
+        a.struct_size = ctypes.sizeof(LinkArgs)
+        a.n_fft, a.cp, a.mod = n_fft, cp, mod_bits(mod)
+        a.seed, a.first_symbol, a.n_sym = seed, first_symbol, n_sym
+        a.sym_per_set = sym_per_set
+        a.sigma = float(sigma)
+        a.llr_weight0 = float(llr_weight)
+        return a
+
+    def link_generate(self, n_fft: int, cp: int, mod, seed: int, first_symbol: int, n_sym: int, sigma: float, *,
+                      chan: Optional[torch.Tensor] = None, sym_per_set: int = 0, want_bits: bool = True,
+                      out_rx: Optional[torch.Tensor] = None):
+        bps = mod_bits(mod)
+        rx = out_rx if out_rx is not None else torch.empty((n_sym, n_fft + cp), dtype=torch.complex64, device=self.torch_device)
+        _need(rx, torch.complex64, "rx", n_sym * (n_fft + cp))
+        bits = torch.empty(n_sym * n_fft * bps // 8, dtype=torch.uint8, device=self.torch_device) if want_bits else None
+        a = self._link_args(n_fft, cp, mod, seed, first_symbol, n_sym, sigma, sym_per_set)
+        if chan is not None:
+            _need(chan, torch.complex64, "chan")
+            a.d_chan = chan.data_ptr()
+        a.d_rx = rx.data_ptr()
+        if bits is not None:
+            a.d_tx_bits = bits.data_ptr()
+        check(self.lib.sdr_link_generate_c32(self._h, ctypes.byref(a)))
+        return rx, bits
+
+    def link_ber(self, n_fft: int, cp: int, mod, seed: int, first_symbol: int, n_sym: int, sigma: float,
+                 llr_weight: float = 1.0, counters: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if counters is None:
+            counters = torch.zeros(8, dtype=torch.int64, device=self.torch_device)
+        _need(counters, torch.int64, "counters", 8)
+        a = self._link_args(n_fft, cp, mod, seed, first_symbol, n_sym, sigma, 0, llr_weight)
+        a.d_counters = counters.data_ptr()
+        check(self.lib.sdr_link_ber_c32(self._h, ctypes.byref(a)))
+        return counters

@@ -1,0 +1,304 @@
+"""GPU parity tests: the HIP path (through the C ABI of libsdr_amd.so) against the CPU oracle on
+identical seeded inputs.  Bars: bit-exact for hard decisions, packed bits, indices and counters;
+FFT outputs and LLRs within 1e-4 of the per-symbol maximum magnitude (north_star), and -- since
+the kernels evaluate the reference's own operation DAG -- exact equality is additionally
+required wherever the test says so."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_vectors.npz")
+TOL = 1e-4
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def rel_err(a, ref):
+    a = np.asarray(a).reshape(ref.shape[0], -1)
+    r = np.asarray(ref).reshape(ref.shape[0], -1)
+    scale = np.abs(r).max(axis=1, keepdims=True)
+    scale[scale == 0] = 1.0
+    return float((np.abs(a - r) / scale).max())
+
+
+def rand_c(rng, shape, dtype=np.complex64):
+    return (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(dtype)
+
+
+# ---- reference gtest cases through the device path ------------------------------------------
+def test_reference_fft_roundtrip_cases(ctx):
+    for dt, tol in ((torch.complex128, 1e-9), (torch.complex64, 1e-5)):
+        ref = torch.arange(8, dtype=dt, device="cuda")
+        x = ref.clone()
+        ctx.fft2_(x)
+        ctx.ifft2_(x)
+        assert (x - ref).abs().max().item() < tol           # fft_test.cpp:10-65
+
+
+def test_reference_non_pow2_fails(ctx):
+    from sdr_amd.capi import SdrError, SDR_ERR_NOT_POW2
+    x = torch.zeros(3, dtype=torch.complex128, device="cuda")
+    with pytest.raises(SdrError) as e:
+        ctx.fft2_(x)                                          # fft_test.cpp:67-72
+    assert e.value.code == SDR_ERR_NOT_POW2 and e.value.message == "The sequence size must be of powers of 2"
+
+
+def test_reference_ofdm_roundtrip_case(ctx):
+    ref = np.array([0, 1 + 1j, 2 + 2j, -1 - 1j, -2 - 2j, -3 - 3j, 1 - 1j, -1 + 1j], dtype=np.complex128)
+    buf = ctx.ofdm_tx(dev(ref), 8, 8)                         # ofdm_test.cpp:11-26
+    res = ctx.ofdm_rx(buf, 8, 8).cpu().numpy()
+    assert np.all(np.abs(res[0] - ref) < 1e-9)
+
+
+def test_reference_hello_case(ctx):
+    data = np.frombuffer(b"Hello", dtype=np.uint8)
+    for dt in (torch.complex128, torch.complex64):
+        sym = ctx.to_constl(dev(data), "16qam", dtype=dt)
+        assert sym.numel() == 10
+        assert ctx.from_constl(sym, "16qam").cpu().numpy().tobytes() == b"Hello"      # ofdm_test.cpp:28-36
+
+
+# ---- fft2 / ifft2: exact DAG parity ------------------------------------------------------
+@pytest.mark.parametrize("n", [1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384])
+def test_fft2_c32_bit_exact(ctx, oracle, n):
+    rng = np.random.default_rng(n)
+    batch = 5 if n <= 4096 else 2
+    x = rand_c(rng, (batch, n))
+    for inverse in (False, True):
+        rc, ref = oracle.fft2(x, inverse)
+        assert rc == 0
+        got = ctx.fft2_(dev(x), inverse).cpu().numpy()
+        assert np.array_equal(got, ref), (n, inverse, rel_err(got, ref))
+
+
+@pytest.mark.parametrize("n", [2, 8, 64, 1024, 4096, 8192])
+def test_fft2_c64_bit_exact(ctx, oracle, n):
+    rng = np.random.default_rng(1000 + n)
+    x = rand_c(rng, (3, n), np.complex128)
+    for inverse in (False, True):
+        rc, ref = oracle.fft2(x, inverse)
+        got = ctx.fft2_(dev(x), inverse).cpu().numpy()
+        assert np.array_equal(got, ref), (n, inverse, rel_err(got, ref))
+
+
+def test_fft2_long_sequences_use_global_path(ctx, oracle):
+    rng = np.random.default_rng(77)
+    for n, dt in ((32768, np.complex64), (16384, np.complex128)):
+        x = rand_c(rng, (2, n), dt)
+        rc, ref = oracle.fft2(x)
+        got = ctx.fft2_(dev(x)).cpu().numpy()
+        assert np.array_equal(got, ref)
+        rc, ref = oracle.fft2(x, True)
+        got = ctx.fft2_(dev(x), True).cpu().numpy()
+        assert np.array_equal(got, ref)
+
+
+def test_fft2_empty_and_unit(ctx):
+    x = torch.tensor([3 + 4j], dtype=torch.complex64, device="cuda")
+    assert ctx.fft2_(x).cpu()[0] == 3 + 4j                   # fft.hpp:91
+    ctx.fft2_(torch.zeros((0,), dtype=torch.complex64, device="cuda"))
+
+
+def test_fft2_golden(ctx):
+    g = np.load(GOLDEN)
+    for n in (8, 64, 1024):
+        assert np.array_equal(ctx.fft2_(dev(g[f"fft_in_c64_{n}"])).cpu().numpy(), g[f"fft_out_c64_{n}"])
+        assert np.array_equal(ctx.fft2_(dev(g[f"fft_in_c64_{n}"]), True).cpu().numpy(), g[f"ifft_out_c64_{n}"])
+        assert np.array_equal(ctx.fft2_(dev(g[f"fft_in_c128_{n}"])).cpu().numpy(), g[f"fft_out_c128_{n}"])
+
+
+# ---- ofdm::rx / tx batched -------------------------------------------------------------------
+@pytest.mark.parametrize("n,cp", [(8, 8), (64, 16), (256, 64), (1024, 256), (2048, 512), (4096, 1024), (128, 0), (512, 37)])
+def test_ofdm_rx_tx_bit_exact(ctx, oracle, n, cp):
+    rng = np.random.default_rng(n + cp)
+    s = 7
+    rx = rand_c(rng, (s, n + cp))
+    rc, ref = oracle.ofdm_rx(rx, n, cp)
+    got = ctx.ofdm_rx(dev(rx), n, cp).cpu().numpy()
+    assert np.array_equal(got, ref), rel_err(got, ref)
+    fr = rand_c(rng, (s, n))
+    rc, ref = oracle.ofdm_tx(fr, n, cp)
+    got = ctx.ofdm_tx(dev(fr), n, cp).cpu().numpy()
+    assert np.array_equal(got, ref), rel_err(got, ref)
+    # round trip property at any size
+    back = ctx.ofdm_rx(ctx.ofdm_tx(dev(fr), n, cp), n, cp).cpu().numpy()
+    assert rel_err(back, fr) < 1e-5
+
+
+# ---- modulation -------------------------------------------------------------------------------
+@pytest.mark.parametrize("bps", [1, 2, 4, 6, 8, 10])
+def test_to_from_constl_bit_exact(ctx, oracle, bps):
+    rng = np.random.default_rng(bps)
+    data = rng.integers(0, 256, 15 * bps, dtype=np.uint8)
+    for dt, npdt in ((torch.complex64, np.complex64), (torch.complex128, np.complex128)):
+        sym = ctx.to_constl(dev(data), bps, dtype=dt)
+        ref = oracle.to_constl(bps, data, dtype=npdt)
+        assert np.array_equal(sym.cpu().numpy(), ref)
+        assert np.array_equal(ctx.from_constl(sym, bps).cpu().numpy(), data)
+    # ragged: symbol counts that do not fill a byte (modulation.hpp:103 drops the tail)
+    sym = oracle.to_constl(bps, data)
+    for n_sym in (1, 3, 5, 7):
+        got = ctx.from_constl(dev(sym[:n_sym]), bps).cpu().numpy()
+        assert np.array_equal(got, oracle.from_constl(bps, sym[:n_sym]))
+
+
+@pytest.mark.parametrize("bps", [2, 4, 6, 8])
+def test_nearest_and_llr_on_boundaries_and_outliers(ctx, oracle, bps):
+    g = np.load(GOLDEN)
+    pts = g[f"demap_pts_{bps}"]
+    idx = ctx.nearest(dev(pts), bps).cpu().numpy().astype(np.uint16)
+    assert np.array_equal(idx, g[f"demap_idx_{bps}"])
+    llr = ctx.soft_demap(dev(pts), bps, 1.75).cpu().numpy()
+    assert np.array_equal(llr, g[f"demap_llr_{bps}"], equal_nan=True)
+
+
+@pytest.mark.parametrize("bps", [1, 2, 4, 6, 8, 10])
+def test_nearest_random_noise_bit_exact(ctx, oracle, bps):
+    rng = np.random.default_rng(40 + bps)
+    pts = rand_c(rng, 200000) * np.float32(0.8)
+    pts[:4] = [complex(np.nan, 0), complex(0, np.nan), 0j, complex(np.inf, 1)]
+    pts[4:2000] *= np.float32(40.0)                            # far outliers: rounding-created ties
+    idx = ctx.nearest(dev(pts), bps).cpu().numpy().astype(np.uint16)
+    assert np.array_equal(idx, oracle.nearest(bps, pts))
+    if bps in (2, 4):
+        p64 = pts.astype(np.complex128)
+        got = ctx.from_constl(dev(p64[: 8 * 1000]), bps).cpu().numpy()
+        assert np.array_equal(got, oracle.from_constl(bps, p64[: 8 * 1000]))
+    llr = ctx.soft_demap(dev(pts[4:]), bps, 0.37).cpu().numpy()
+    assert np.array_equal(llr, oracle.soft_demap(bps, pts[4:], 0.37))
+
+
+def test_zf_taps(ctx, oracle):
+    rng = np.random.default_rng(8)
+    h = rand_c(rng, 4096) * np.float32(0.7)
+    taps, w = ctx.zf_taps(dev(h), 6, 17.5)
+    rt, rw = oracle.zf_taps(6, h, 17.5)
+    assert np.array_equal(taps.cpu().numpy(), rt) and np.array_equal(w.cpu().numpy(), rw)
+
+
+# ---- fused receive path ------------------------------------------------------------------------
+CASES = [(64, 16, 2), (64, 16, 4), (128, 32, 6), (256, 64, 8), (512, 128, 4), (1024, 256, 4), (1024, 256, 6),
+         (2048, 512, 6), (4096, 1024, 8), (1024, 256, 2), (4096, 1024, 2), (2048, 0, 8), (32, 8, 4), (1024, 100, 1), (256, 64, 10)]
+
+
+@pytest.mark.parametrize("n,cp,bps", CASES)
+def test_demod_parity(ctx, oracle, n, cp, bps):
+    from sdr_amd.link import noise_sigma, llr_weight
+    n_sym = 29 if n <= 1024 else 9
+    ebn0 = {1: 4.0, 2: 5.0, 4: 9.0, 6: 14.0, 8: 19.0, 10: 24.0}[bps]
+    sigma = np.float32(noise_sigma(n, bps, ebn0))
+    w = np.float32(llr_weight(bps, ebn0))
+    rx, bits = oracle.link_generate(n, cp, bps, 1234 + n, 5, n_sym, sigma)
+    ref = oracle.demod(rx, n, cp, bps, weight=w)
+    counters = torch.zeros(8, dtype=torch.int64, device="cuda")
+    out = ctx.demod(dev(rx), n, cp, bps, llr_weight=float(w), want_llr=True, want_hard=True, want_fft=True,
+                    ref_hard=dev(bits), counters=counters)
+    assert np.array_equal(out.hard.cpu().numpy(), ref["hard"])                 # hard decisions: bit exact
+    assert rel_err(out.fft.cpu().numpy(), ref["fft"]) <= TOL                    # FFT: 1e-4 relative
+    assert np.array_equal(out.fft.cpu().numpy(), ref["fft"])                    # ... and in fact identical
+    got_llr = out.llr.cpu().numpy()
+    assert rel_err(got_llr, ref["llr"]) <= TOL                                  # LLR: 1e-4 relative
+    assert np.array_equal(got_llr, ref["llr"])
+    c = counters.cpu().numpy()
+    assert c[0] == oracle.count_bit_errors(ref["hard"], bits) and c[0] > 0      # error count: bit exact
+    assert c[1] == n_sym * n * bps and c[3] == n_sym * n and c[4] == n_sym
+
+
+@pytest.mark.parametrize("n,cp,bps", [(64, 16, 2), (1024, 256, 4), (2048, 512, 6), (4096, 1024, 8)])
+def test_demod_with_equaliser_sets(ctx, oracle, n, cp, bps):
+    from sdr_amd.link import noise_sigma
+    rng = np.random.default_rng(n)
+    n_sym, per = 30, 14
+    n_sets = (n_sym + per - 1) // per
+    h = (rand_c(rng, (n_sets, n)) * np.float32(np.sqrt(0.5))).astype(np.complex64)
+    h[np.abs(h) < 0.1] += np.float32(0.3)
+    sigma = np.float32(noise_sigma(n, bps, 30.0))
+    rx, bits = oracle.link_generate(n, cp, bps, 99, 0, n_sym, sigma, chan=h, sym_per_set=per)
+    taps, wgt = oracle.zf_taps(bps, h, 50.0)
+    ref = oracle.demod(rx, n, cp, bps, eq=taps, weight=wgt, sym_per_set=per)
+    dtaps, dw = ctx.zf_taps(dev(h.ravel()), bps, 50.0)
+    out = ctx.demod(dev(rx), n, cp, bps, eq=dtaps, llr_weight=dw, sym_per_set=per, want_hard=True, want_fft=True)
+    assert np.array_equal(out.hard.cpu().numpy(), ref["hard"])
+    assert np.array_equal(out.fft.cpu().numpy(), ref["fft"])
+    assert rel_err(out.llr.cpu().numpy(), ref["llr"]) <= TOL
+    assert np.array_equal(out.llr.cpu().numpy(), ref["llr"])
+    # high SNR + zero forcing: almost every bit must come back
+    assert oracle.count_bit_errors(ref["hard"], bits) < 0.02 * bits.size * 8
+
+
+def test_demod_outputs_are_optional(ctx, oracle):
+    rx, bits = oracle.link_generate(1024, 256, 4, 3, 0, 4, 0.01)
+    ref = oracle.demod(rx, 1024, 256, 4, weight=2.0)
+    a = ctx.demod(dev(rx), 1024, 256, 4, llr_weight=2.0, want_llr=False, want_hard=True)
+    assert a.llr is None and np.array_equal(a.hard.cpu().numpy(), ref["hard"])
+    b = ctx.demod(dev(rx), 1024, 256, 4, llr_weight=2.0, want_llr=True, want_hard=False)
+    assert b.hard is None and np.array_equal(b.llr.cpu().numpy(), ref["llr"])
+    c = ctx.demod(dev(rx), 1024, 256, 4, want_llr=False, want_fft=True)
+    assert np.array_equal(c.fft.cpu().numpy(), ref["fft"])
+
+
+# ---- generator / AWGN / Monte-Carlo link ---------------------------------------------------------
+@pytest.mark.parametrize("n,cp,bps", [(64, 16, 2), (1024, 256, 4), (2048, 512, 6), (4096, 1024, 8), (256, 64, 1), (512, 128, 10)])
+def test_link_generate_bit_exact(ctx, oracle, n, cp, bps):
+    n_sym = 6
+    rx, bits = ctx.link_generate(n, cp, bps, seed=7, first_symbol=3, n_sym=n_sym, sigma=0.02)
+    rrx, rbits = oracle.link_generate(n, cp, bps, 7, 3, n_sym, 0.02)
+    assert np.array_equal(bits.cpu().numpy(), rbits)
+    assert np.array_equal(rx.cpu().numpy(), rrx), rel_err(rx.cpu().numpy(), rrx)
+
+
+def test_link_generate_with_channel(ctx, oracle):
+    rng = np.random.default_rng(1)
+    n, cp, bps, per = 256, 64, 4, 14
+    h = rand_c(rng, (3, n))
+    rx, bits = ctx.link_generate(n, cp, bps, 5, 14, 30, 0.01, chan=dev(h), sym_per_set=per)
+    rrx, rbits = oracle.link_generate(n, cp, bps, 5, 14, 30, 0.01, chan=h, sym_per_set=per)
+    assert np.array_equal(bits.cpu().numpy(), rbits) and np.array_equal(rx.cpu().numpy(), rrx)
+
+
+@pytest.mark.parametrize("n,cp,bps,ebn0", [(64, 16, 2, 4.0), (1024, 256, 4, 8.0), (1024, 256, 6, 12.0), (1024, 256, 8, 16.0),
+                                           (2048, 512, 6, 12.0), (4096, 1024, 8, 18.0), (256, 64, 2, 3.0)])
+def test_link_ber_counters_bit_exact(ctx, oracle, n, cp, bps, ebn0):
+    from sdr_amd.link import noise_sigma, llr_weight
+    n_sym = 28 if n <= 1024 else 14
+    sigma = np.float32(noise_sigma(n, bps, ebn0))
+    w = np.float32(llr_weight(bps, ebn0))
+    got = ctx.link_ber(n, cp, bps, seed=21, first_symbol=42, n_sym=n_sym, sigma=float(sigma), llr_weight=float(w)).cpu().numpy()
+    ref = oracle.link_ber(n, cp, bps, 21, 42, n_sym, sigma, w)
+    assert np.array_equal(got.astype(np.uint64), ref), (got, ref)
+    assert got[0] > 0
+
+
+def test_link_ber_is_split_invariant_and_accumulates(ctx):
+    from sdr_amd.link import noise_sigma, llr_weight
+    n, cp, bps = 1024, 256, 4
+    sigma, w = noise_sigma(n, bps, 8.0), llr_weight(bps, 8.0)
+    whole = ctx.link_ber(n, cp, bps, 5, 0, 56, sigma, w).cpu().numpy()
+    acc = torch.zeros(8, dtype=torch.int64, device="cuda")
+    for first, cnt in ((0, 14), (14, 28), (42, 14)):
+        ctx.link_ber(n, cp, bps, 5, first, cnt, sigma, w, counters=acc)
+    assert np.array_equal(acc.cpu().numpy(), whole)
+
+
+def test_large_batch_properties(ctx):
+    """Full-size behaviour through size-independent properties: tx -> rx round trip and
+    linearity of the batched FFT on a batch far larger than the oracle could check."""
+    n, cp, s = 1024, 256, 16384
+    g = torch.Generator(device="cuda").manual_seed(3)
+    a = torch.randn((s, n), dtype=torch.float32, device="cuda", generator=g).to(torch.complex64)
+    a = a + 1j * torch.randn((s, n), dtype=torch.float32, device="cuda", generator=g)
+    back = ctx.ofdm_rx(ctx.ofdm_tx(a, n, cp), n, cp)
+    assert ((back - a).abs().amax(dim=1) / a.abs().amax(dim=1)).max().item() < 1e-5
+    b = torch.roll(a, 1, dims=0)
+    fa = ctx.ofdm_rx(torch.cat([torch.zeros((s, cp), dtype=a.dtype, device="cuda"), a], dim=1), n, cp)
+    fb = ctx.ofdm_rx(torch.cat([torch.zeros((s, cp), dtype=a.dtype, device="cuda"), b], dim=1), n, cp)
+    fab = ctx.ofdm_rx(torch.cat([torch.zeros((s, cp), dtype=a.dtype, device="cuda"), a + b], dim=1), n, cp)
+    assert ((fab - fa - fb).abs().amax(dim=1) / fab.abs().amax(dim=1)).max().item() < 1e-5
+    ref = torch.fft.fft(a[:64].to(torch.complex128), dim=1)
+    assert ((fa[:64] - ref).abs().amax(dim=1) / ref.abs().amax(dim=1)).max().item() < 5e-6

@@ -1,0 +1,100 @@
+"""CPU tests of the host-side driver logic (sdr_amd/link.py) including a world_size-2 gloo run
+of the sharded sweep, with the CPU oracle standing in for the GPU counting kernel."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_frames_tiles_range():
+    from sdr_amd.link import shard_frames
+    for n in (0, 1, 7, 8, 1000, 1001):
+        for world in (1, 2, 3, 8):
+            spans = [shard_frames(n, r, world) for r in range(world)]
+            pos = 0
+            for first, count in spans:
+                assert first == pos
+                pos += count
+            assert pos == n
+            assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
+
+
+def test_noise_scaling():
+    from sdr_amd.link import noise_sigma, llr_weight, grid_energy
+    # per-bin complex noise variance N * 2*sigma^2 must equal N0 = 1/(bps*EbN0)
+    for n, bps, db in ((64, 2, 10.0), (1024, 4, 12.0), (4096, 8, 24.0)):
+        s = noise_sigma(n, bps, db)
+        n0 = 1.0 / (bps * 10 ** (db / 10))
+        assert abs(n * 2 * s * s - n0) < 1e-12
+        assert abs(llr_weight(bps, db) - 1.0 / (grid_energy(bps) * n0)) < 1e-9
+
+
+def test_plan_sweep_uses_disjoint_frames():
+    from sdr_amd.link import plan_sweep, SYMBOLS_PER_FRAME
+    pts = plan_sweep([2, 4], {2: [0, 1, 2], 4: [0, 4]}, 1024, 1e8)
+    pos = 0
+    for p in pts:
+        assert p.first_frame == pos
+        pos += p.n_frames
+    assert sum(p.n_frames * SYMBOLS_PER_FRAME * 1024 * p.mod_bits for p in pts) >= 1e8
+
+
+def _oracle_count(n_fft, cp, seed):
+    from oracle import binding as o
+
+    def fn(p, g0, n_sym, sigma, w):
+        return [int(v) for v in o.link_ber(n_fft, cp, p.mod_bits, seed, g0, n_sym, np.float32(sigma), np.float32(w))]
+    return fn
+
+
+def test_sweep_counts_do_not_depend_on_world_size():
+    from sdr_amd.link import plan_sweep, run_sweep
+    n_fft, cp, seed = 64, 16, 5
+    pts = plan_sweep([2, 4], {2: [2.0, 4.0], 4: [6.0]}, n_fft, 3e5)
+    one = run_sweep(pts, n_fft, cp, seed, 0, 1, _oracle_count(n_fft, cp, seed))
+    parts = [run_sweep(pts, n_fft, cp, seed, r, 3, _oracle_count(n_fft, cp, seed)) for r in range(3)]
+    for i in range(len(pts)):
+        summed = [sum(p.counters[i][j] for p in parts) for j in range(8)]
+        assert summed == one.counters[i]
+        assert one.counters[i][0] > 0
+
+
+def _gloo_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from sdr_amd.link import plan_sweep, run_sweep, torch_all_reduce
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_fft, cp, seed = 64, 16, 9
+    pts = plan_sweep([2, 6], {2: [3.0], 6: [10.0, 12.0]}, n_fft, 2e5)
+    res = run_sweep(pts, n_fft, cp, seed, rank, world, _oracle_count(n_fft, cp, seed), torch_all_reduce)
+    q.put((rank, res.counters))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sweep_gloo_world2_matches_single_rank():
+    import torch.multiprocessing as mp
+    from sdr_amd.link import plan_sweep, run_sweep
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n_fft, cp, seed = 64, 16, 9
+    pts = plan_sweep([2, 6], {2: [3.0], 6: [10.0, 12.0]}, n_fft, 2e5)
+    ref = run_sweep(pts, n_fft, cp, seed, 0, 1, _oracle_count(n_fft, cp, seed))
+    assert got[0] == ref.counters and got[1] == ref.counters
