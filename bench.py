@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the fused receive path (CP removal -> FFT -> equalise -> max-log LLR).
+
+A "step" is one pass of the hot path over one batch of synthetic OFDM symbols that is already
+resident in HBM (generated on the device by the library's own frame generator + AWGN).
+Default workload = BASELINE.json configs[1]: FFT-1024, cp 256, 16-QAM soft LLR, 1 Mi symbols per
+GPU.  With N GPUs every rank processes its own batch (weak scaling; OFDM symbols are independent,
+so there is no data-path collective); rank 0 prints ONE JSON line.
+
+  python bench.py --gpus 1 --steps 10 --warmup 3
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+WORKLOADS = {
+    # name: (n_fft, cp, bits/subcarrier, symbols per GPU, Eb/N0 dB, per-subcarrier equaliser)
+    "fft1024_16qam_1M": (1024, 256, 4, 1 << 20, 12.0, False),      # configs[1] -- the bench line
+    "fft1024_64qam_1M": (1024, 256, 6, 1 << 20, 16.0, False),      # north_star headline target (>= 70 % HBM)
+    "fft2048_64qam_eq": (2048, 512, 6, 1 << 18, 18.0, True),       # configs[2] shape, one resident chunk
+    "fft4096_256qam": (4096, 1024, 8, 1 << 17, 24.0, False),       # configs[3] shape, per-GPU chunk
+    "fft64_qpsk": (64, 16, 2, 1 << 22, 10.0, False),               # configs[0] shape on the GPU
+}
+
+
+def algorithmic_bytes_per_symbol(n_fft, bps):
+    """payload samples read (CP skipped) + fp32 LLR written."""
+    return 8 * n_fft + 4 * n_fft * bps
+
+
+def make_inputs(ctx, torch, n_fft, cp, bps, n_sym, ebn0_db, with_eq, seed, first_symbol):
+    from sdr_amd.link import noise_sigma, llr_weight, SYMBOLS_PER_FRAME
+    sigma = noise_sigma(n_fft, bps, ebn0_db)
+    w0 = llr_weight(bps, ebn0_db)
+    rx = torch.empty((n_sym, n_fft + cp), dtype=torch.complex64, device="cuda")
+    chan = eq = wgt = None
+    per = 0
+    if with_eq:
+        per = SYMBOLS_PER_FRAME
+        n_sets = (n_sym + per - 1) // per + 1
+        g = torch.Generator(device="cuda").manual_seed(seed)
+        chan = torch.complex(torch.randn((n_sets, n_fft), device="cuda", generator=g), torch.randn((n_sets, n_fft), device="cuda", generator=g)) * (0.5 ** 0.5)
+        chan = chan.to(torch.complex64).contiguous()
+        n0 = 1.0 / (bps * 10 ** (ebn0_db / 10))
+        eq, wgt = ctx.zf_taps(chan.view(-1), bps, 1.0 / n0)
+    chunk = 1 << 15
+    if with_eq:
+        chunk = (chunk // per) * per
+    for s0 in range(0, n_sym, chunk):
+        n = min(chunk, n_sym - s0)
+        ch = None
+        if with_eq:
+            ch = chan[s0 // per:]
+        ctx.link_generate(n_fft, cp, bps, seed, first_symbol + s0, n, sigma, chan=ch, sym_per_set=per, want_bits=False, out_rx=rx[s0:s0 + n])
+    torch.cuda.synchronize()
+    return rx, eq, wgt, w0, per
+
+
+def cpu_baseline(n_fft, cp, bps, budget_s=12.0):
+    """The CPU oracle (port of the reference path: ofdm::rx + nearest, plus the same LLR
+    definition), one thread as the reference runs, on a bounded sample of the same workload."""
+    import numpy as np
+    from oracle import binding as oracle
+    from sdr_amd.link import noise_sigma, llr_weight
+    n_s = max(64, min(2048, (1 << 21) // n_fft))
+    rx, _ = oracle.link_generate(n_fft, cp, bps, 2, 0, n_s, np.float32(noise_sigma(n_fft, bps, 12.0)))
+    w = np.float32(llr_weight(bps, 12.0))
+    oracle.demod(rx[:8], n_fft, cp, bps, weight=w, want_fft=False)
+    done, t0 = 0, time.perf_counter()
+    while True:
+        oracle.demod(rx, n_fft, cp, bps, weight=w, want_fft=False)
+        done += n_s
+        dt = time.perf_counter() - t0
+        if dt >= budget_s:
+            break
+    return {"value": done / dt, "unit": "OFDM symbols/s", "cores": 1, "kind": "port",
+            "sample": f"{done} symbols ({n_s}-symbol batch x {done // n_s} passes) of FFT-{n_fft}/{bps}-bit LLR+hard demod in {dt:.1f} s, 1 thread of {os.cpu_count()} host CPUs"}
+
+
+def time_workload(ctx, torch, dist, name, steps, warmup, world, rank, n_sym_override=None):
+    n_fft, cp, bps, n_sym, ebn0, with_eq = WORKLOADS[name]
+    if n_sym_override:
+        n_sym = n_sym_override
+    first = rank * ((n_sym + 13) // 14) * 14      # whole frames per rank, disjoint global symbol ranges
+    rx, eq, wgt, w0, per = make_inputs(ctx, torch, n_fft, cp, bps, n_sym, ebn0, with_eq, seed=2, first_symbol=first)
+    llr = torch.empty((n_sym, n_fft, bps), dtype=torch.float32, device="cuda")
+
+    def step():
+        ctx.demod(rx, n_fft, cp, bps, eq=eq, llr_weight=(wgt if wgt is not None else w0), sym_per_set=per, out_llr=llr)
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    t0 = time.perf_counter()
+    ev[0].record()
+    for i in range(steps):
+        step()
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    launch_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
+    avg_launch_s = sum(launch_ms) / len(launch_ms) / 1e3
+    b_sym = algorithmic_bytes_per_symbol(n_fft, bps)
+    achieved = b_sym * n_sym / avg_launch_s / 1e9
+    res = {
+        "n_fft": n_fft, "cp": cp, "bps": bps, "n_sym": n_sym, "elapsed": elapsed,
+        "sym_per_s": world * n_sym * steps / elapsed,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "bytes_per_symbol": b_sym, "symbols_per_launch": n_sym, "avg_launch_ms": avg_launch_s * 1e3},
+    }
+    del rx, llr, eq, wgt
+    torch.cuda.empty_cache()
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="fft1024_16qam_1M", choices=sorted(WORKLOADS))
+    ap.add_argument("--symbols", type=int, default=0, help="override symbols per GPU (debug)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra 64-QAM headline measurement")
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+        local_rank = 0
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+
+    from sdr_amd.ops import Context
+    ctx = Context(local_rank)
+    main_res = time_workload(ctx, torch, dist, args.workload, args.steps, args.warmup, world, rank, args.symbols or None)
+    extra = {}
+    if world == 1 and not args.no_extra and args.workload == "fft1024_16qam_1M" and not args.symbols:
+        r = time_workload(ctx, torch, dist, "fft1024_64qam_1M", max(3, args.steps // 2), 2, 1, 0)
+        extra["fft1024_64qam_1M"] = {"sym_per_s": r["sym_per_s"], "llr_gbit_per_s": r["sym_per_s"] * r["n_fft"] * r["bps"] / 1e9,
+                                     "hbm_frac": r["roofline"]["frac"], "achieved_GBs": r["roofline"]["achieved"]}
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        cpu = cpu_baseline(main_res["n_fft"], main_res["cp"], main_res["bps"])
+    if rank == 0:
+        n_fft, bps = main_res["n_fft"], main_res["bps"]
+        line = {
+            "metric": "demodulated OFDM symbols/s (fused CP-removal + FFT + equalise + max-log LLR)",
+            "value": main_res["sym_per_s"],
+            "unit": "OFDM symbols/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": main_res["elapsed"] / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic (device frame generator: Philox bits -> QAM -> IFFT+CP -> AWGN)",
+            "config": {"workload": args.workload, "n_fft": n_fft, "cp": main_res["cp"], "bits_per_subcarrier": bps,
+                       "symbols_per_gpu": main_res["n_sym"], "sharding": f"independent symbol batches x{world}"},
+            "llr_gbit_per_s": main_res["sym_per_s"] * n_fft * bps / 1e9,
+            "roofline": main_res["roofline"],
+            "cpu_baseline": cpu,
+            "extra": extra,
+        }
+        print(json.dumps(line))
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

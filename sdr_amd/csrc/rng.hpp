@@ -103,7 +103,7 @@ __device__ inline void sincos_turn(uint32_t k24, float& s, float& c)
 __device__ inline float2 gaussian_pair(uint32_t x1, uint32_t x2, float sigma)
 {
     const float u1 = static_cast<float>((x1 >> 8) + 1u) * 5.9604644775390625e-08f;
-    const float rad = __fsqrt_rn(-2.0f * ln_unit(u1));
+    const float rad = sqrtf(-2.0f * ln_unit(u1));   // correctly rounded (hipcc default); __fsqrt_rn is the native 1-ulp form
     float s, c;
     sincos_turn(x2 >> 8, s, c);
     const float a = sigma * rad;

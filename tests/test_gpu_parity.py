@@ -27,6 +27,10 @@ def rel_err(a, ref):
     return float((np.abs(a - r) / scale).max())
 
 
+def same(a, b, **kw):
+    return bool(np.array_equal(np.asarray(a), np.asarray(b), **kw))
+
+
 def rand_c(rng, shape, dtype=np.complex64):
     return (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(dtype)
 
@@ -34,7 +38,7 @@ def rand_c(rng, shape, dtype=np.complex64):
 # ---- reference gtest cases through the device path ------------------------------------------
 def test_reference_fft_roundtrip_cases(ctx):
     for dt, tol in ((torch.complex128, 1e-9), (torch.complex64, 1e-5)):
-        ref = torch.arange(8, dtype=dt, device="cuda")
+        ref = torch.arange(8, device="cuda").to(dt)
         x = ref.clone()
         ctx.fft2_(x)
         ctx.ifft2_(x)
@@ -74,7 +78,7 @@ def test_fft2_c32_bit_exact(ctx, oracle, n):
         rc, ref = oracle.fft2(x, inverse)
         assert rc == 0
         got = ctx.fft2_(dev(x), inverse).cpu().numpy()
-        assert np.array_equal(got, ref), (n, inverse, rel_err(got, ref))
+        assert same(got, ref), (n, inverse, rel_err(got, ref))
 
 
 @pytest.mark.parametrize("n", [2, 8, 64, 1024, 4096, 8192])
@@ -84,7 +88,7 @@ def test_fft2_c64_bit_exact(ctx, oracle, n):
     for inverse in (False, True):
         rc, ref = oracle.fft2(x, inverse)
         got = ctx.fft2_(dev(x), inverse).cpu().numpy()
-        assert np.array_equal(got, ref), (n, inverse, rel_err(got, ref))
+        assert same(got, ref), (n, inverse, rel_err(got, ref))
 
 
 def test_fft2_long_sequences_use_global_path(ctx, oracle):
@@ -93,10 +97,10 @@ def test_fft2_long_sequences_use_global_path(ctx, oracle):
         x = rand_c(rng, (2, n), dt)
         rc, ref = oracle.fft2(x)
         got = ctx.fft2_(dev(x)).cpu().numpy()
-        assert np.array_equal(got, ref)
+        assert same(got, ref)
         rc, ref = oracle.fft2(x, True)
         got = ctx.fft2_(dev(x), True).cpu().numpy()
-        assert np.array_equal(got, ref)
+        assert same(got, ref)
 
 
 def test_fft2_empty_and_unit(ctx):
@@ -108,9 +112,9 @@ def test_fft2_empty_and_unit(ctx):
 def test_fft2_golden(ctx):
     g = np.load(GOLDEN)
     for n in (8, 64, 1024):
-        assert np.array_equal(ctx.fft2_(dev(g[f"fft_in_c64_{n}"])).cpu().numpy(), g[f"fft_out_c64_{n}"])
-        assert np.array_equal(ctx.fft2_(dev(g[f"fft_in_c64_{n}"]), True).cpu().numpy(), g[f"ifft_out_c64_{n}"])
-        assert np.array_equal(ctx.fft2_(dev(g[f"fft_in_c128_{n}"])).cpu().numpy(), g[f"fft_out_c128_{n}"])
+        assert same(ctx.fft2_(dev(g[f"fft_in_c64_{n}"])).cpu().numpy(), g[f"fft_out_c64_{n}"])
+        assert same(ctx.fft2_(dev(g[f"fft_in_c64_{n}"]), True).cpu().numpy(), g[f"ifft_out_c64_{n}"])
+        assert same(ctx.fft2_(dev(g[f"fft_in_c128_{n}"])).cpu().numpy(), g[f"fft_out_c128_{n}"])
 
 
 # ---- ofdm::rx / tx batched -------------------------------------------------------------------
@@ -121,11 +125,11 @@ def test_ofdm_rx_tx_bit_exact(ctx, oracle, n, cp):
     rx = rand_c(rng, (s, n + cp))
     rc, ref = oracle.ofdm_rx(rx, n, cp)
     got = ctx.ofdm_rx(dev(rx), n, cp).cpu().numpy()
-    assert np.array_equal(got, ref), rel_err(got, ref)
+    assert same(got, ref), rel_err(got, ref)
     fr = rand_c(rng, (s, n))
     rc, ref = oracle.ofdm_tx(fr, n, cp)
     got = ctx.ofdm_tx(dev(fr), n, cp).cpu().numpy()
-    assert np.array_equal(got, ref), rel_err(got, ref)
+    assert same(got, ref), rel_err(got, ref)
     # round trip property at any size
     back = ctx.ofdm_rx(ctx.ofdm_tx(dev(fr), n, cp), n, cp).cpu().numpy()
     assert rel_err(back, fr) < 1e-5
@@ -139,13 +143,13 @@ def test_to_from_constl_bit_exact(ctx, oracle, bps):
     for dt, npdt in ((torch.complex64, np.complex64), (torch.complex128, np.complex128)):
         sym = ctx.to_constl(dev(data), bps, dtype=dt)
         ref = oracle.to_constl(bps, data, dtype=npdt)
-        assert np.array_equal(sym.cpu().numpy(), ref)
-        assert np.array_equal(ctx.from_constl(sym, bps).cpu().numpy(), data)
+        assert same(sym.cpu().numpy(), ref)
+        assert same(ctx.from_constl(sym, bps).cpu().numpy(), data)
     # ragged: symbol counts that do not fill a byte (modulation.hpp:103 drops the tail)
     sym = oracle.to_constl(bps, data)
     for n_sym in (1, 3, 5, 7):
         got = ctx.from_constl(dev(sym[:n_sym]), bps).cpu().numpy()
-        assert np.array_equal(got, oracle.from_constl(bps, sym[:n_sym]))
+        assert same(got, oracle.from_constl(bps, sym[:n_sym]))
 
 
 @pytest.mark.parametrize("bps", [2, 4, 6, 8])
@@ -153,9 +157,9 @@ def test_nearest_and_llr_on_boundaries_and_outliers(ctx, oracle, bps):
     g = np.load(GOLDEN)
     pts = g[f"demap_pts_{bps}"]
     idx = ctx.nearest(dev(pts), bps).cpu().numpy().astype(np.uint16)
-    assert np.array_equal(idx, g[f"demap_idx_{bps}"])
+    assert same(idx, g[f"demap_idx_{bps}"])
     llr = ctx.soft_demap(dev(pts), bps, 1.75).cpu().numpy()
-    assert np.array_equal(llr, g[f"demap_llr_{bps}"], equal_nan=True)
+    assert same(llr, g[f"demap_llr_{bps}"], equal_nan=True)
 
 
 @pytest.mark.parametrize("bps", [1, 2, 4, 6, 8, 10])
@@ -165,13 +169,13 @@ def test_nearest_random_noise_bit_exact(ctx, oracle, bps):
     pts[:4] = [complex(np.nan, 0), complex(0, np.nan), 0j, complex(np.inf, 1)]
     pts[4:2000] *= np.float32(40.0)                            # far outliers: rounding-created ties
     idx = ctx.nearest(dev(pts), bps).cpu().numpy().astype(np.uint16)
-    assert np.array_equal(idx, oracle.nearest(bps, pts))
+    assert same(idx, oracle.nearest(bps, pts))
     if bps in (2, 4):
         p64 = pts.astype(np.complex128)
         got = ctx.from_constl(dev(p64[: 8 * 1000]), bps).cpu().numpy()
-        assert np.array_equal(got, oracle.from_constl(bps, p64[: 8 * 1000]))
+        assert same(got, oracle.from_constl(bps, p64[: 8 * 1000]))
     llr = ctx.soft_demap(dev(pts[4:]), bps, 0.37).cpu().numpy()
-    assert np.array_equal(llr, oracle.soft_demap(bps, pts[4:], 0.37))
+    assert same(llr, oracle.soft_demap(bps, pts[4:], 0.37))
 
 
 def test_zf_taps(ctx, oracle):
@@ -179,7 +183,7 @@ def test_zf_taps(ctx, oracle):
     h = rand_c(rng, 4096) * np.float32(0.7)
     taps, w = ctx.zf_taps(dev(h), 6, 17.5)
     rt, rw = oracle.zf_taps(6, h, 17.5)
-    assert np.array_equal(taps.cpu().numpy(), rt) and np.array_equal(w.cpu().numpy(), rw)
+    assert same(taps.cpu().numpy(), rt) and same(w.cpu().numpy(), rw)
 
 
 # ---- fused receive path ------------------------------------------------------------------------
@@ -199,12 +203,12 @@ def test_demod_parity(ctx, oracle, n, cp, bps):
     counters = torch.zeros(8, dtype=torch.int64, device="cuda")
     out = ctx.demod(dev(rx), n, cp, bps, llr_weight=float(w), want_llr=True, want_hard=True, want_fft=True,
                     ref_hard=dev(bits), counters=counters)
-    assert np.array_equal(out.hard.cpu().numpy(), ref["hard"])                 # hard decisions: bit exact
+    assert same(out.hard.cpu().numpy(), ref["hard"])                 # hard decisions: bit exact
     assert rel_err(out.fft.cpu().numpy(), ref["fft"]) <= TOL                    # FFT: 1e-4 relative
-    assert np.array_equal(out.fft.cpu().numpy(), ref["fft"])                    # ... and in fact identical
+    assert same(out.fft.cpu().numpy(), ref["fft"])                    # ... and in fact identical
     got_llr = out.llr.cpu().numpy()
     assert rel_err(got_llr, ref["llr"]) <= TOL                                  # LLR: 1e-4 relative
-    assert np.array_equal(got_llr, ref["llr"])
+    assert same(got_llr, ref["llr"])
     c = counters.cpu().numpy()
     assert c[0] == oracle.count_bit_errors(ref["hard"], bits) and c[0] > 0      # error count: bit exact
     assert c[1] == n_sym * n * bps and c[3] == n_sym * n and c[4] == n_sym
@@ -224,10 +228,10 @@ def test_demod_with_equaliser_sets(ctx, oracle, n, cp, bps):
     ref = oracle.demod(rx, n, cp, bps, eq=taps, weight=wgt, sym_per_set=per)
     dtaps, dw = ctx.zf_taps(dev(h.ravel()), bps, 50.0)
     out = ctx.demod(dev(rx), n, cp, bps, eq=dtaps, llr_weight=dw, sym_per_set=per, want_hard=True, want_fft=True)
-    assert np.array_equal(out.hard.cpu().numpy(), ref["hard"])
-    assert np.array_equal(out.fft.cpu().numpy(), ref["fft"])
+    assert same(out.hard.cpu().numpy(), ref["hard"])
+    assert same(out.fft.cpu().numpy(), ref["fft"])
     assert rel_err(out.llr.cpu().numpy(), ref["llr"]) <= TOL
-    assert np.array_equal(out.llr.cpu().numpy(), ref["llr"])
+    assert same(out.llr.cpu().numpy(), ref["llr"])
     # high SNR + zero forcing: almost every bit must come back
     assert oracle.count_bit_errors(ref["hard"], bits) < 0.02 * bits.size * 8
 
@@ -236,11 +240,11 @@ def test_demod_outputs_are_optional(ctx, oracle):
     rx, bits = oracle.link_generate(1024, 256, 4, 3, 0, 4, 0.01)
     ref = oracle.demod(rx, 1024, 256, 4, weight=2.0)
     a = ctx.demod(dev(rx), 1024, 256, 4, llr_weight=2.0, want_llr=False, want_hard=True)
-    assert a.llr is None and np.array_equal(a.hard.cpu().numpy(), ref["hard"])
+    assert a.llr is None and same(a.hard.cpu().numpy(), ref["hard"])
     b = ctx.demod(dev(rx), 1024, 256, 4, llr_weight=2.0, want_llr=True, want_hard=False)
-    assert b.hard is None and np.array_equal(b.llr.cpu().numpy(), ref["llr"])
+    assert b.hard is None and same(b.llr.cpu().numpy(), ref["llr"])
     c = ctx.demod(dev(rx), 1024, 256, 4, want_llr=False, want_fft=True)
-    assert np.array_equal(c.fft.cpu().numpy(), ref["fft"])
+    assert same(c.fft.cpu().numpy(), ref["fft"])
 
 
 # ---- generator / AWGN / Monte-Carlo link ---------------------------------------------------------
@@ -249,8 +253,8 @@ def test_link_generate_bit_exact(ctx, oracle, n, cp, bps):
     n_sym = 6
     rx, bits = ctx.link_generate(n, cp, bps, seed=7, first_symbol=3, n_sym=n_sym, sigma=0.02)
     rrx, rbits = oracle.link_generate(n, cp, bps, 7, 3, n_sym, 0.02)
-    assert np.array_equal(bits.cpu().numpy(), rbits)
-    assert np.array_equal(rx.cpu().numpy(), rrx), rel_err(rx.cpu().numpy(), rrx)
+    assert same(bits.cpu().numpy(), rbits)
+    assert same(rx.cpu().numpy(), rrx), rel_err(rx.cpu().numpy(), rrx)
 
 
 def test_link_generate_with_channel(ctx, oracle):
@@ -259,7 +263,7 @@ def test_link_generate_with_channel(ctx, oracle):
     h = rand_c(rng, (3, n))
     rx, bits = ctx.link_generate(n, cp, bps, 5, 14, 30, 0.01, chan=dev(h), sym_per_set=per)
     rrx, rbits = oracle.link_generate(n, cp, bps, 5, 14, 30, 0.01, chan=h, sym_per_set=per)
-    assert np.array_equal(bits.cpu().numpy(), rbits) and np.array_equal(rx.cpu().numpy(), rrx)
+    assert same(bits.cpu().numpy(), rbits) and same(rx.cpu().numpy(), rrx)
 
 
 @pytest.mark.parametrize("n,cp,bps,ebn0", [(64, 16, 2, 4.0), (1024, 256, 4, 8.0), (1024, 256, 6, 12.0), (1024, 256, 8, 16.0),
@@ -271,7 +275,7 @@ def test_link_ber_counters_bit_exact(ctx, oracle, n, cp, bps, ebn0):
     w = np.float32(llr_weight(bps, ebn0))
     got = ctx.link_ber(n, cp, bps, seed=21, first_symbol=42, n_sym=n_sym, sigma=float(sigma), llr_weight=float(w)).cpu().numpy()
     ref = oracle.link_ber(n, cp, bps, 21, 42, n_sym, sigma, w)
-    assert np.array_equal(got.astype(np.uint64), ref), (got, ref)
+    assert same(got.astype(np.uint64), ref), (got, ref)
     assert got[0] > 0
 
 
@@ -283,7 +287,7 @@ def test_link_ber_is_split_invariant_and_accumulates(ctx):
     acc = torch.zeros(8, dtype=torch.int64, device="cuda")
     for first, cnt in ((0, 14), (14, 28), (42, 14)):
         ctx.link_ber(n, cp, bps, 5, first, cnt, sigma, w, counters=acc)
-    assert np.array_equal(acc.cpu().numpy(), whole)
+    assert same(acc.cpu().numpy(), whole)
 
 
 def test_large_batch_properties(ctx):
