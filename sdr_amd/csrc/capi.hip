@@ -27,7 +27,8 @@ int ofdm_rx_device(sdr_ctx* ctx, bool is_double, const void* d_in, size_t n_fft,
     if (n_sym == 0 || n_fft == 0) return SDR_OK;
     if (!is_pow2(n_fft)) return fail(SDR_ERR_NOT_POW2, "%s", kPow2Message);
     if (!d_in || !d_out) return fail(SDR_ERR_INVALID, "null device pointer");
-    if (!is_double && n_fft <= 0xFFFFFFFFu && cp <= 0xFFFFFFFFu && rx_fused_supported(static_cast<uint32_t>(n_fft), 0))
+    if (!is_double && n_fft <= 4096 && cp <= 0xFFFFFFFFu && cp % 2 == 0 && rx_fused_supported(static_cast<uint32_t>(n_fft), 0) &&
+        reinterpret_cast<uintptr_t>(d_in) % 16 == 0 && reinterpret_cast<uintptr_t>(d_out) % 16 == 0)
         return rx_fft_only_launch(ctx, d_in, static_cast<uint32_t>(n_fft), static_cast<uint32_t>(cp), n_sym, d_out);
     return is_double ? fft_generic_f64(ctx, d_in, d_out, n_fft, false, n_fft + cp, cp, n_fft, 0, 0, n_sym)
                      : fft_generic_f32(ctx, d_in, d_out, n_fft, false, n_fft + cp, cp, n_fft, 0, 0, n_sym);
@@ -187,7 +188,7 @@ int sdr_ofdm_demod_c32(sdr_ctx* ctx, const sdr_demod_args* args)
     if (!is_pow2(a.n_fft)) return fail(SDR_ERR_NOT_POW2, "%s", kPow2Message);
     if (!a.d_rx) return fail(SDR_ERR_INVALID, "null d_rx");
     if ((a.d_ref_hard != nullptr) != (a.d_counters != nullptr)) return fail(SDR_ERR_INVALID, "d_ref_hard and d_counters must be given together");
-    if (rx_fused_supported(a.n_fft, a.mod)) return rx_fused_launch(ctx, a);
+    if (rx_fused_supported(a.n_fft, a.mod) && rx_fused_layout_ok(a)) return rx_fused_launch(ctx, a);
     // generic sizes: reference-network FFT into memory, then the element-wise back end
     void* d_fft = a.d_fft;
     if (!d_fft) SDR_TRY(get_staging(ctx, 5, size_t(a.n_sym) * a.n_fft * sizeof(float2), &d_fft));

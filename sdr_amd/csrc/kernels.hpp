@@ -22,6 +22,7 @@ int demap_after_fft(sdr_ctx* ctx, const sdr_demod_args& a, const void* d_fft);
 
 // rx_fused.hip: the tuned fused receive kernel (fp32, n_fft 64..4096).
 bool rx_fused_supported(uint32_t n_fft, uint32_t mod);
+bool rx_fused_layout_ok(const sdr_demod_args& a);
 int rx_fused_launch(sdr_ctx* ctx, const sdr_demod_args& a);
 int rx_fft_only_launch(sdr_ctx* ctx, const void* d_in, uint32_t n_fft, uint32_t cp, uint64_t n_sym, void* d_out);
 

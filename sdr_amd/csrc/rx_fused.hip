@@ -1,8 +1,93 @@
-// rx_fused.hip -- placeholder until the tuned kernel lands (next commit).
+// rx_fused.hip -- host side of the tuned fused receive kernel: eligibility, argument packing,
+// dispatch to the per-size instantiations (rx_fused_inst.hip).
 #include "common.hpp"
 #include "kernels.hpp"
+#include "qam.hpp"
+#include "rx_fused.hpp"
+
+#include <cmath>
+
 namespace sdr {
-bool rx_fused_supported(uint32_t, uint32_t) { return false; }
-int rx_fused_launch(sdr_ctx*, const sdr_demod_args&) { return fail(SDR_ERR_UNSUPPORTED, "fused kernel not built"); }
-int rx_fft_only_launch(sdr_ctx*, const void*, uint32_t, uint32_t, uint64_t, void*) { return fail(SDR_ERR_UNSUPPORTED, "fused kernel not built"); }
+
+int rx_fused_dispatch_6(sdr_ctx*, const RxParams&, int, bool);
+int rx_fused_dispatch_7(sdr_ctx*, const RxParams&, int, bool);
+int rx_fused_dispatch_8(sdr_ctx*, const RxParams&, int, bool);
+int rx_fused_dispatch_9(sdr_ctx*, const RxParams&, int, bool);
+int rx_fused_dispatch_10(sdr_ctx*, const RxParams&, int, bool);
+int rx_fused_dispatch_11(sdr_ctx*, const RxParams&, int, bool);
+int rx_fused_dispatch_12(sdr_ctx*, const RxParams&, int, bool);
+
+namespace {
+
+bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+int dispatch(sdr_ctx* ctx, unsigned log2n, const RxParams& p, int mod, bool full)
+{
+    switch (log2n) {
+        case 6: return rx_fused_dispatch_6(ctx, p, mod, full);
+        case 7: return rx_fused_dispatch_7(ctx, p, mod, full);
+        case 8: return rx_fused_dispatch_8(ctx, p, mod, full);
+        case 9: return rx_fused_dispatch_9(ctx, p, mod, full);
+        case 10: return rx_fused_dispatch_10(ctx, p, mod, full);
+        case 11: return rx_fused_dispatch_11(ctx, p, mod, full);
+        case 12: return rx_fused_dispatch_12(ctx, p, mod, full);
+        default: return fail(SDR_ERR_UNSUPPORTED, "n_fft = 2^%u has no fused kernel", log2n);
+    }
 }
+
+} // namespace
+
+// mod = 0 asks about the FFT-only form.
+bool rx_fused_supported(uint32_t n_fft, uint32_t mod)
+{
+    if (!is_pow2(n_fft) || n_fft < 64 || n_fft > 4096) return false;
+    return mod == 0 || mod == 1 || mod == 2 || mod == 4 || mod == 6 || mod == 8;
+}
+
+// The vector accesses of the kernel need 16-byte aligned buffers and an even CP; anything else
+// goes to the generic engines (same arithmetic).
+bool rx_fused_layout_ok(const sdr_demod_args& a)
+{
+    if (a.cp % 2 != 0) return false;
+    if (!aligned(a.d_rx, 16) || !aligned(a.d_llr, 16) || !aligned(a.d_fft, 16) || !aligned(a.d_eq, 16) || !aligned(a.d_llr_weight, 8)) return false;
+    if (!aligned(a.d_hard, 4)) return false;
+    return true;
+}
+
+int rx_fused_launch(sdr_ctx* ctx, const sdr_demod_args& a)
+{
+    const void* tw = nullptr;
+    SDR_TRY(get_twiddles(ctx, a.n_fft, false, false, &tw));
+    RxParams p = {};
+    p.rx = static_cast<const float2*>(a.d_rx);
+    p.tw = static_cast<const float2*>(tw);
+    p.eq = static_cast<const float2*>(a.d_eq);
+    p.wgt = a.d_llr_weight;
+    p.llr = a.d_llr;
+    p.hard = a.d_hard;
+    p.fft = static_cast<float2*>(a.d_fft);
+    p.ref = a.d_ref_hard;
+    p.counters = reinterpret_cast<unsigned long long*>(a.d_counters);
+    p.n_sym = a.n_sym;
+    p.cp = a.cp;
+    p.sym_per_set = a.sym_per_set;
+    p.w0 = a.llr_weight0;
+    p.inorm = std::sqrt(static_cast<float>(grid_energy(static_cast<int>(a.mod))));
+    const bool full = a.d_hard || a.d_fft || a.d_counters || !a.d_llr || a.mod == 1;
+    return dispatch(ctx, ilog2(a.n_fft), p, static_cast<int>(a.mod), full);
+}
+
+int rx_fft_only_launch(sdr_ctx* ctx, const void* d_in, uint32_t n_fft, uint32_t cp, uint64_t n_sym, void* d_out)
+{
+    const void* tw = nullptr;
+    SDR_TRY(get_twiddles(ctx, n_fft, false, false, &tw));
+    RxParams p = {};
+    p.rx = static_cast<const float2*>(d_in);
+    p.tw = static_cast<const float2*>(tw);
+    p.fft = static_cast<float2*>(d_out);
+    p.n_sym = n_sym;
+    p.cp = cp;
+    return dispatch(ctx, ilog2(n_fft), p, 0, true);
+}
+
+} // namespace sdr

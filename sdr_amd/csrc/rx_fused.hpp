@@ -1,0 +1,456 @@
+// rx_fused.hpp -- the tuned fused receive kernel (fp32, n_fft = 64..4096):
+//   CP removal -> FFT (reference radix-2 DIT network) -> one-tap equalise -> max-log LLR
+//   (+ optional nearest() hard bits, FFT bins, BER/LLR counters).
+//
+// Replaces, for whole batches of OFDM symbols, the reference call chain
+//   ofdm::rx (lib/inc/ofdm.hpp:37-43) -> fft::fft2 (lib/inc/fft.hpp:87-155)
+//   -> modulation::from_constl / nearest (lib/inc/modulation.hpp:49-112)
+// with the equaliser and LLR steps (no reference counterpart) inserted between them.
+//
+// Arithmetic: exactly the reference's operation DAG.  After the bit reversal (lib/inc/fft.hpp:
+// 35-51, here a free index remap on the global load) stage c pairs positions differing in bit c
+// and multiplies the upper one by the table twiddle W_c[pos mod 2^c] as four products
+// (:130-134), then adds/subtracts (:136-137).  The plan (fft_plans.hpp) only decides where the
+// positions live: each thread keeps E of them in registers and runs 3-4 stages per pass with no
+// data movement; between passes the array crosses LDS once in a bank-conflict-free layout.
+// Built with -ffp-contract=off, so every product and sum rounds separately as on the CPU.
+//
+// Mapping: TPS = N/E threads per symbol; a workgroup is max(64, TPS) threads = 64/TPS symbols
+// (small N) or one symbol (N >= 1024).  Workgroups are persistent and stride over the batch.
+// Twiddles: first pass = lane-uniform (scalar registers), middle pass = small LDS table, last
+// pass = per-thread registers loaded once per workgroup.
+// HBM traffic per symbol: 8*N bytes read (CP never fetched) + 4*N*bps bytes of LLR written.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <utility>
+
+#include "fft_plans.hpp"
+#include "qam.hpp"
+
+namespace sdr {
+
+struct RxParams {
+    const float2* rx;            // n_sym x (N + cp)
+    const float2* tw;            // N-1 forward twiddles (reference recurrence)
+    const float2* eq;            // n_sets x N or null
+    const float* wgt;            // n_sets x N or null
+    float* llr;                  // n_sym x N x bps or null
+    uint8_t* hard;               // packed bits or null                 (FULL only)
+    float2* fft;                 // n_sym x N or null                   (FULL / FFT-only)
+    const uint8_t* ref;          // reference packed bits or null       (FULL only)
+    unsigned long long* counters;// 8 counters or null                  (FULL only)
+    unsigned long long n_sym;
+    uint32_t cp;
+    uint32_t sym_per_set;
+    float w0;
+    float inorm;
+};
+
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    [&]<int... I>(std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, N>{});
+}
+
+template <int LOG2N>
+struct PlanOps {
+    using P = FftPlan<LOG2N>;
+    static constexpr int kN = 1 << LOG2N;
+    static constexpr int kLogE = P::kLogE;
+    static constexpr int kE = 1 << kLogE;
+    static constexpr int kNT = P::kThreadBits;
+    static constexpr int kTPS = 1 << kNT;                       // threads per symbol
+    static constexpr int kWG = kTPS < 64 ? 64 : kTPS;            // workgroup size
+    static constexpr int kSPW = kWG / kTPS;                      // symbols per workgroup
+    static constexpr int kPasses = P::kPasses;
+    static constexpr int kLast = kPasses - 1;
+
+    static constexpr int reg_pos(int pass, int m)
+    {
+        int p = 0;
+        for (int i = 0; i < kLogE; ++i)
+            if ((m >> i) & 1) p |= 1 << P::kRegBit[pass][i];
+        return p;
+    }
+    static constexpr int reg_addr(int ex, int pass, int m)
+    {
+        int a = 0;
+        for (int i = 0; i < kLogE; ++i)
+            if ((m >> i) & 1) a += P::kWeight[ex][P::kRegBit[pass][i]];
+        return a;
+    }
+    static constexpr int bitrev(int v, int bits)
+    {
+        int r = 0;
+        for (int i = 0; i < bits; ++i)
+            if ((v >> i) & 1) r |= 1 << (bits - 1 - i);
+        return r;
+    }
+    // register-bit index that carries stage c in this pass
+    static constexpr int bfly_bit(int pass, int c)
+    {
+        for (int i = 0; i < kLogE; ++i)
+            if (P::kRegBit[pass][i] == c) return i;
+        return -1;
+    }
+    static constexpr int insert_zero(int h, int bit)
+    {
+        const int lo = h & ((1 << bit) - 1);
+        return ((h >> bit) << (bit + 1)) | lo;
+    }
+    // number of group registers that are adjacent in the output (last pass) / input (first pass)
+    static constexpr int kGroupOut = 1 << (kLogE - P::kR[kLast]);
+    static constexpr int kGroupIn = 1 << (kLogE - P::kR[0]);
+    static constexpr int max_sym_bytes()
+    {
+        int m = 0;
+        for (int k = 0; k < kPasses - 1; ++k) m = P::kSymBytes[k] > m ? P::kSymBytes[k] : m;
+        return (m + 15) & ~15;
+    }
+    // middle-pass twiddle table in LDS: entries of stages c0..c0+r-1 of pass 1 (3-pass plans only)
+    static constexpr int kMidFirst = kPasses == 3 ? (1 << P::kC0[1]) - 1 : 0;
+    static constexpr int kMidCount = kPasses == 3 ? (1 << (P::kC0[1] + P::kR[1])) - (1 << P::kC0[1]) : 0;
+    // last-pass register twiddles: per stage, one per distinct low-register pattern
+    static constexpr int last_low_mask(int c)   // register-bit indices whose position bit is below c
+    {
+        int mask = 0;
+        for (int i = 0; i < kLogE; ++i)
+            if (P::kRegBit[kLast][i] < c) mask |= 1 << i;
+        return mask;
+    }
+    static constexpr int popcount(int v) { int c = 0; for (; v; v &= v - 1) ++c; return c; }
+    static constexpr int pext(int v, int mask)
+    {
+        int r = 0, o = 0;
+        for (int i = 0; i < kLogE; ++i)
+            if ((mask >> i) & 1) { if ((v >> i) & 1) r |= 1 << o; ++o; }
+        return r;
+    }
+    static constexpr int pdep(int v, int mask)
+    {
+        int r = 0, o = 0;
+        for (int i = 0; i < kLogE; ++i)
+            if ((mask >> i) & 1) { if ((v >> o) & 1) r |= 1 << i; ++o; }
+        return r;
+    }
+    static constexpr int last_tw_offset(int s)   // slot offset of stage s (0-based inside the last pass)
+    {
+        int off = 0;
+        for (int q = 0; q < s; ++q) off += 1 << popcount(last_low_mask(P::kC0[kLast] + q));
+        return off;
+    }
+    static constexpr int kLastTwCount = last_tw_offset(P::kR[kLast]);
+
+    template <int PASS>
+    static __device__ __forceinline__ int thr_pos(int t)
+    {
+        int p = 0;
+        static_for<kNT>([&](auto U) { constexpr int u = U; constexpr int pb = P::kThrBit[PASS][u]; p |= ((t >> u) & 1) << pb; });
+        return p;
+    }
+    template <int EX, int PASS>
+    static __device__ __forceinline__ int thr_addr(int t)
+    {
+        int a = 0;
+        static_for<kNT>([&](auto U) { constexpr int u = U; constexpr int wgt = P::kWeight[EX][P::kThrBit[PASS][u]]; a += ((t >> u) & 1) * wgt; });
+        return a;
+    }
+};
+
+__device__ __forceinline__ void bfly(float2& even, float2& odd, const float2 w)
+{
+    const float tr = odd.x * w.x - odd.y * w.y;
+    const float ti = odd.x * w.y + odd.y * w.x;
+    const float ar = even.x + tr, ai = even.y + ti;
+    const float br = even.x - tr, bi = even.y - ti;
+    even.x = ar; even.y = ai;
+    odd.x = br; odd.y = bi;
+}
+
+// stores COUNT consecutive floats with the widest access the chunk alignment allows
+template <int COUNT>
+__device__ __forceinline__ void store_floats(float* __restrict__ dst, const float* v)
+{
+    if constexpr (COUNT % 4 == 0) {
+        static_for<COUNT / 4>([&](auto I) { constexpr int i = I; reinterpret_cast<float4*>(dst)[i] = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]); });
+    } else if constexpr (COUNT % 2 == 0) {
+        static_for<COUNT / 2>([&](auto I) { constexpr int i = I; reinterpret_cast<float2*>(dst)[i] = make_float2(v[2 * i], v[2 * i + 1]); });
+    } else {
+        static_for<COUNT>([&](auto I) { constexpr int i = I; dst[i] = v[i]; });
+    }
+}
+
+__device__ __forceinline__ unsigned ref_bits(const uint8_t* __restrict__ s, size_t pos, int nbits)
+{
+    const size_t first = pos >> 3, last = (pos + nbits - 1) >> 3;
+    unsigned acc = 0;
+    for (size_t b = first; b <= last; ++b) acc = (acc << 8) | s[b];
+    const unsigned span = static_cast<unsigned>(last - first + 1) * 8u;
+    return (acc >> (span - static_cast<unsigned>(pos & 7) - static_cast<unsigned>(nbits))) & ((1u << nbits) - 1u);
+}
+
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// MI + MQ == 0: FFT only (bins to p.fft).  FULL: every output optional at run time.
+template <int LOG2N, int MI, int MQ, bool FULL>
+__global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) rx_fused_kernel(const RxParams p)
+{
+    using O = PlanOps<LOG2N>;
+    using P = typename O::P;
+    constexpr int N = O::kN, E = O::kE, TPS = O::kTPS, SPW = O::kSPW, LAST = O::kLast;
+    constexpr int BPS = MI + MQ;
+    constexpr bool DEMAP = BPS > 0;
+    constexpr int SYM_BYTES = O::max_sym_bytes();
+    constexpr int DATA_BYTES = SYM_BYTES * SPW;
+    constexpr int TW_BYTES = O::kMidCount * 8;
+    constexpr int IDX_BYTES = (FULL && DEMAP) ? N * SPW : 0;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[DATA_BYTES + TW_BYTES + IDX_BYTES + 16];
+    unsigned char* lds_data = lds;
+    const float2* lds_tw = reinterpret_cast<const float2*>(lds + DATA_BYTES);
+    unsigned char* lds_idx = lds + DATA_BYTES + TW_BYTES;
+
+    const int tid = threadIdx.x;
+    const int slot = tid / TPS;
+    const int t = tid % TPS;
+
+    // ---- per-workgroup set-up: twiddles ----
+    float2 tw_first[(1 << P::kR[0]) - 1];
+    static_for<(1 << P::kR[0]) - 1>([&](auto I) { constexpr int i = I; tw_first[i] = p.tw[i]; });
+    if constexpr (O::kMidCount > 0) {
+        float2* dst = reinterpret_cast<float2*>(lds + DATA_BYTES);
+        for (int i = tid; i < O::kMidCount; i += O::kWG) dst[i] = p.tw[O::kMidFirst + i];
+    }
+    const int pos_last = O::template thr_pos<LAST>(t);
+    float2 tw_last[O::kLastTwCount];
+    {
+        const int jt = pos_last & ((1 << P::kC0[LAST]) - 1);
+        static_for<P::kR[LAST]>([&](auto S) {
+            constexpr int s = S;
+            constexpr int c = P::kC0[LAST] + s;
+            constexpr int mask = O::last_low_mask(c);
+            static_for<(1 << O::popcount(mask))>([&](auto K) {
+                constexpr int key = K;
+                constexpr int jm = O::reg_pos(LAST, O::pdep(key, mask)) & ((1 << c) - 1);
+                tw_last[O::last_tw_offset(s) + key] = p.tw[(1 << c) - 1 + jm + jt];
+            });
+        });
+    }
+    // loop-invariant address parts
+    int in_thread = 0;   // input index contributed by the thread bits: bitrev_n(thr_pos<0>(t))
+    static_for<O::kNT>([&](auto U) { constexpr int u = U; constexpr int ib = LOG2N - 1 - P::kThrBit[0][u]; in_thread |= ((t >> u) & 1) << ib; });
+    const int wr0 = slot * SYM_BYTES + O::template thr_addr<0, 0>(t);
+    const int rd0 = slot * SYM_BYTES + O::template thr_addr<0, 1>(t);
+    int wr1 = 0, rd1 = 0, mid_jt = 0;
+    if constexpr (O::kPasses == 3) {
+        wr1 = slot * SYM_BYTES + O::template thr_addr<1, 1>(t);
+        rd1 = slot * SYM_BYTES + O::template thr_addr<1, 2>(t);
+        mid_jt = O::template thr_pos<1>(t) & ((1 << P::kC0[1]) - 1);
+    }
+
+    unsigned long long c_bit = 0, c_sym = 0, c_abs = 0, c_sign = 0, c_n = 0;
+
+    const unsigned long long n_groups = (p.n_sym + SPW - 1) / SPW;
+    const size_t in_stride = static_cast<size_t>(N) + p.cp;
+    if constexpr (O::kMidCount > 0) __syncthreads();
+
+    for (unsigned long long grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        unsigned long long sym = grp * SPW + slot;
+        const bool active = sym < p.n_sym;
+        if (!active) sym = p.n_sym - 1;
+
+        // ---- pass 0: load (CP skipped, bit reversal folded into the index) ----
+        float2 x[E];
+        {
+            const float2* src = p.rx + sym * in_stride + p.cp + in_thread;
+            constexpr int GI = O::kGroupIn;
+            static_for<E / GI>([&](auto Q) {
+                constexpr int q = Q;   // butterfly register bits of pass 0 (low kR[0] register bits)
+                constexpr int idx0 = O::bitrev(O::reg_pos(0, q), LOG2N);
+                static_assert(GI == 1 || GI == 2, "plans load one or two adjacent samples per register group");
+                if constexpr (GI == 1) {
+                    x[q] = src[idx0];
+                } else if constexpr (GI == 2) {
+                    // register bit kR[0] is the group bit: adjacent input samples
+                    const float4 v = *reinterpret_cast<const float4*>(src + idx0);
+                    x[q] = make_float2(v.x, v.y);
+                    x[q | (1 << P::kR[0])] = make_float2(v.z, v.w);
+                }
+            });
+        }
+        static_for<P::kR[0]>([&](auto S) {
+            constexpr int c = P::kC0[0] + S;
+            constexpr int bi = O::bfly_bit(0, c);
+            static_for<E / 2>([&](auto H) {
+                constexpr int m0 = O::insert_zero(H, bi), m1 = m0 | (1 << bi);
+                constexpr int j = O::reg_pos(0, m0) & ((1 << c) - 1);
+                bfly(x[m0], x[m1], tw_first[(1 << c) - 1 + j]);
+            });
+        });
+        // ---- exchange 0 ----
+        static_for<E>([&](auto M) { constexpr int m = M; *reinterpret_cast<float2*>(lds_data + wr0 + O::reg_addr(0, 0, m)) = x[m]; });
+        __syncthreads();
+        static_for<E>([&](auto M) { constexpr int m = M; x[m] = *reinterpret_cast<const float2*>(lds_data + rd0 + O::reg_addr(0, 1, m)); });
+
+        if constexpr (O::kPasses == 3) {
+            // ---- pass 1 (middle): twiddles from the LDS table ----
+            static_for<P::kR[1]>([&](auto S) {
+                constexpr int c = P::kC0[1] + S;
+                constexpr int bi = O::bfly_bit(1, c);
+                static_for<E / 2>([&](auto H) {
+                    constexpr int m0 = O::insert_zero(H, bi), m1 = m0 | (1 << bi);
+                    constexpr int jm = O::reg_pos(1, m0) & ((1 << c) - 1);
+                    const float2 w = lds_tw[(1 << c) - 1 - O::kMidFirst + jm + mid_jt];
+                    bfly(x[m0], x[m1], w);
+                });
+            });
+            __syncthreads();   // all reads of exchange 0 done before the region is rewritten
+            static_for<E>([&](auto M) { constexpr int m = M; *reinterpret_cast<float2*>(lds_data + wr1 + O::reg_addr(1, 1, m)) = x[m]; });
+            __syncthreads();
+            static_for<E>([&](auto M) { constexpr int m = M; x[m] = *reinterpret_cast<const float2*>(lds_data + rd1 + O::reg_addr(1, 2, m)); });
+        }
+
+        // ---- last pass: twiddles from registers ----
+        static_for<P::kR[LAST]>([&](auto S) {
+            constexpr int s = S;
+            constexpr int c = P::kC0[LAST] + s;
+            constexpr int bi = O::bfly_bit(LAST, c);
+            constexpr int mask = O::last_low_mask(c);
+            static_for<E / 2>([&](auto H) {
+                constexpr int m0 = O::insert_zero(H, bi), m1 = m0 | (1 << bi);
+                bfly(x[m0], x[m1], tw_last[O::last_tw_offset(s) + O::pext(m0, mask)]);
+            });
+        });
+
+        // ---- epilogue: bins are in natural order, k = reg_pos(LAST, m) | pos_last ----
+        constexpr int GO = O::kGroupOut;   // adjacent bins held in registers m = GO*h + (0..GO-1)
+        const size_t bin0 = static_cast<size_t>(sym) * N;
+        if constexpr (!DEMAP || FULL) {
+            if (p.fft && active) {
+                static_for<E / GO>([&](auto Hh) {
+                    constexpr int h = Hh;
+                    const int k = O::reg_pos(LAST, h * GO) | pos_last;
+                    if constexpr (GO == 2) {
+                        *reinterpret_cast<float4*>(p.fft + bin0 + k) = make_float4(x[h * GO].x, x[h * GO].y, x[h * GO + 1].x, x[h * GO + 1].y);
+                    } else {
+                        static_for<GO>([&](auto G) { constexpr int g = G; p.fft[bin0 + k + g] = x[h * GO + g]; });
+                    }
+                });
+            }
+        }
+        if constexpr (DEMAP) {
+            const size_t set = p.sym_per_set ? static_cast<size_t>(sym / p.sym_per_set) : 0;
+            const float2* eq = p.eq ? p.eq + set * N : nullptr;
+            const float* wgt = p.wgt ? p.wgt + set * N : nullptr;
+            static_for<E / GO>([&](auto Hh) {
+                constexpr int h = Hh;
+                const int k = O::reg_pos(LAST, h * GO) | pos_last;
+                float l[GO * BPS];
+                unsigned idx[GO];
+                static_for<GO>([&](auto G) {
+                    constexpr int g = G;
+                    float2 y = x[h * GO + g];
+                    if (eq) {
+                        const float2 gk = eq[k + g];
+                        const float er = y.x * gk.x - y.y * gk.y;
+                        const float ei = y.x * gk.y + y.y * gk.x;
+                        y.x = er; y.y = ei;
+                    }
+                    const float w = wgt ? wgt[k + g] : p.w0;
+                    idx[g] = demap_point<float, MI, MQ, true, FULL>(y.x, y.y, p.inorm, w, l + g * BPS);
+                });
+                if (p.llr && active) store_floats<GO * BPS>(p.llr + (bin0 + k) * BPS, l);
+                if constexpr (FULL) {
+                    if (p.hard) static_for<GO>([&](auto G) { constexpr int g = G; lds_idx[slot * N + k + g] = static_cast<unsigned char>(idx[g]); });
+                    if (p.counters && active) {
+                        static_for<GO>([&](auto G) {
+                            constexpr int g = G;
+                            const unsigned ref = ref_bits(p.ref, (bin0 + k + g) * BPS, BPS);
+                            const unsigned diff = ref ^ idx[g];
+                            c_bit += __popc(diff);
+                            c_sym += (diff != 0);
+                            c_n += 1;
+                            static_for<BPS>([&](auto B) {
+                                constexpr int b = B;
+                                const float lv = l[g * BPS + b];
+                                float a = fabsf(lv) * 1024.0f;
+                                a = (a < 1073741824.0f) ? a : 1073741824.0f;
+                                c_abs += static_cast<unsigned long long>(static_cast<long long>(a));
+                                c_sign += (((ref >> (BPS - 1 - b)) & 1u) != (lv < 0.0f ? 1u : 0u));
+                            });
+                        });
+                    }
+                }
+            });
+            if constexpr (FULL) {
+                if (p.hard) {
+                    __syncthreads();
+                    constexpr int WORDS = N * BPS / 32;
+                    constexpr int CNT = (32 + BPS - 1) / BPS + 1;
+                    if (active) {
+                        uint32_t* out = reinterpret_cast<uint32_t*>(p.hard + bin0 * BPS / 8);
+                        for (int j = t; j < WORDS; j += TPS) {
+                            const int k0 = (32 * j) / BPS;
+                            const int off = 32 * j - k0 * BPS;
+                            unsigned long long acc = 0;
+#pragma unroll
+                            for (int i = 0; i < CNT; ++i) {
+                                const int kk = (k0 + i < N) ? k0 + i : N - 1;
+                                acc = (acc << BPS) | lds_idx[slot * N + kk];
+                            }
+                            const uint32_t word = static_cast<uint32_t>(acc >> (CNT * BPS - off - 32));
+                            out[j] = __builtin_bswap32(word);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();   // LDS regions are reused by the next symbol group
+    }
+
+    if constexpr (FULL && DEMAP) {
+        if (p.counters) {
+            c_bit = wave_sum_u64(c_bit); c_sym = wave_sum_u64(c_sym); c_abs = wave_sum_u64(c_abs);
+            c_sign = wave_sum_u64(c_sign); c_n = wave_sum_u64(c_n);
+            if ((tid & 63) == 0) {
+                atomicAdd(&p.counters[0], c_bit);
+                atomicAdd(&p.counters[1], c_n * BPS);
+                atomicAdd(&p.counters[2], c_sym);
+                atomicAdd(&p.counters[3], c_n);
+                atomicAdd(&p.counters[5], c_abs);
+                atomicAdd(&p.counters[6], c_sign);
+            }
+            if (blockIdx.x == 0 && tid == 0) atomicAdd(&p.counters[4], p.n_sym);
+        }
+    }
+}
+
+template <int LOG2N, int MI, int MQ, bool FULL>
+int launch_rx_fused(sdr_ctx* ctx, const RxParams& p)
+{
+    using O = PlanOps<LOG2N>;
+    auto kern = rx_fused_kernel<LOG2N, MI, MQ, FULL>;
+    static int blocks_per_cu = 0;
+    if (blocks_per_cu == 0) {
+        int nb = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, O::kWG, 0);
+        if (e != hipSuccess) return fail_hip(e, "hipOccupancyMaxActiveBlocksPerMultiprocessor");
+        blocks_per_cu = nb > 0 ? nb : 1;
+    }
+    const unsigned long long n_groups = (p.n_sym + O::kSPW - 1) / O::kSPW;
+    unsigned long long blocks = static_cast<unsigned long long>(ctx->num_cu) * blocks_per_cu;
+    if (blocks > n_groups) blocks = n_groups;
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(O::kWG), 0, ctx->stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, "rx_fused_kernel launch");
+    return SDR_OK;
+}
+
+} // namespace sdr
