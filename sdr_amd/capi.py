@@ -11,7 +11,7 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_size_t, c_uint8, c_uint16, c_uint32, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsdr_amd.so")
+LIB_PATH = os.environ.get("SDR_AMD_LIB") or os.path.join(_HERE, "lib", "libsdr_amd.so")   # SDR_AMD_LIB: A/B builds while tuning
 
 SDR_OK = 0
 SDR_ERR_NOT_POW2 = -1

@@ -25,6 +25,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdio>
+#include <cstdlib>
 #include <utility>
 
 #include "fft_plans.hpp"
@@ -47,6 +49,7 @@ struct RxParams {
     uint32_t sym_per_set;
     float w0;
     float inorm;
+    uint32_t groups_per_wg;      // consecutive symbol groups handled by one workgroup
 };
 
 template <int N, typename F>
@@ -183,6 +186,30 @@ __device__ __forceinline__ void store_floats(float* __restrict__ dst, const floa
     }
 }
 
+typedef float sdr_v4f __attribute__((ext_vector_type(4)));
+typedef float sdr_v2f __attribute__((ext_vector_type(2)));
+
+// streaming (non-temporal) stores for outputs that are written once and never re-read here;
+// only used where one wave instruction covers a contiguous span (see membench: scattered NT is slow)
+__device__ __forceinline__ void stream_store4(float* dst, float a, float b, float c, float d)
+{
+    sdr_v4f v = {a, b, c, d};
+    __builtin_nontemporal_store(v, reinterpret_cast<sdr_v4f*>(dst));
+}
+__device__ __forceinline__ void stream_store2(float* dst, float a, float b)
+{
+    sdr_v2f v = {a, b};
+    __builtin_nontemporal_store(v, reinterpret_cast<sdr_v2f*>(dst));
+}
+
+// LLR staging through LDS: per-lane chunk of C floats -> lane-contiguous vectors (coalesced stores)
+constexpr int stage_stride_bytes(int c) { return c == 6 ? 24 : c == 8 ? 48 : c == 12 ? 48 : c == 16 ? 80 : c * 4; }
+#ifdef SDR_NO_STAGE8
+constexpr bool stage_wanted(int c) { return c == 6 || c == 12 || c == 16; }
+#else
+constexpr bool stage_wanted(int c) { return c == 6 || c == 8 || c == 12 || c == 16; }
+#endif
+
 __device__ __forceinline__ unsigned ref_bits(const uint8_t* __restrict__ s, size_t pos, int nbits)
 {
     const size_t first = pos >> 3, last = (pos + nbits - 1) >> 3;
@@ -199,9 +226,15 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
     return v;
 }
 
+#ifdef SDR_WPE
+#define SDR_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(SDR_WPE, SDR_WPE)))
+#else
+#define SDR_WAVES_ATTR
+#endif
+
 // MI + MQ == 0: FFT only (bins to p.fft).  FULL: every output optional at run time.
 template <int LOG2N, int MI, int MQ, bool FULL>
-__global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) rx_fused_kernel(const RxParams p)
+__global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) SDR_WAVES_ATTR rx_fused_kernel(const RxParams p)
 {
     using O = PlanOps<LOG2N>;
     using P = typename O::P;
@@ -212,7 +245,13 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) rx_fused_kernel(const RxP
     constexpr int DATA_BYTES = SYM_BYTES * SPW;
     constexpr int TW_BYTES = O::kMidCount * 8;
     constexpr int IDX_BYTES = (FULL && DEMAP) ? N * SPW : 0;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[DATA_BYTES + TW_BYTES + IDX_BYTES + 16];
+    constexpr int CHUNK = O::kGroupOut * BPS;                      // LLR floats per lane per output block
+    constexpr bool STAGE = DEMAP && SPW == 1 && stage_wanted(CHUNK);
+    constexpr int STG_STRIDE = stage_stride_bytes(CHUNK);
+    constexpr int STG_WAVE_BYTES = STAGE ? 64 * STG_STRIDE : 0;
+    constexpr int STG_BYTES = STG_WAVE_BYTES * (O::kWG / 64);
+    constexpr int STG_OFF = (DATA_BYTES + TW_BYTES + IDX_BYTES + 15) & ~15;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[STG_OFF + STG_BYTES + 16];
     unsigned char* lds_data = lds;
     const float2* lds_tw = reinterpret_cast<const float2*>(lds + DATA_BYTES);
     unsigned char* lds_idx = lds + DATA_BYTES + TW_BYTES;
@@ -261,30 +300,46 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) rx_fused_kernel(const RxP
     const size_t in_stride = static_cast<size_t>(N) + p.cp;
     if constexpr (O::kMidCount > 0) __syncthreads();
 
-    for (unsigned long long grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+    // global load of one symbol into registers: CP skipped, bit reversal folded into the index
+    auto load_symbol = [&](unsigned long long grp_, float2 (&dst)[E]) {
+        unsigned long long s_ = grp_ * SPW + slot;
+        if (s_ >= p.n_sym) s_ = p.n_sym - 1;
+        const float2* src = p.rx + s_ * in_stride + p.cp + in_thread;
+        constexpr int GI = O::kGroupIn;
+        static_assert(GI == 1 || GI == 2, "plans load one or two adjacent samples per register group");
+        static_for<E / GI>([&](auto Q) {
+            constexpr int q = Q;   // butterfly register bits of pass 0 (low kR[0] register bits)
+            constexpr int idx0 = O::bitrev(O::reg_pos(0, q), LOG2N);
+            if constexpr (GI == 1) {
+                dst[q] = src[idx0];
+            } else {
+                // register bit kR[0] is the group bit: adjacent input samples
+                const float4 v = *reinterpret_cast<const float4*>(src + idx0);
+                dst[q] = make_float2(v.x, v.y);
+                dst[q | (1 << P::kR[0])] = make_float2(v.z, v.w);
+            }
+        });
+    };
+
+    const unsigned long long grp_begin = static_cast<unsigned long long>(blockIdx.x) * p.groups_per_wg;
+    const unsigned long long grp_end = (grp_begin + p.groups_per_wg < n_groups) ? grp_begin + p.groups_per_wg : n_groups;
+    float2 x[E];
+#ifdef SDR_PREFETCH
+    float2 xn[E];
+    if (grp_begin < grp_end) load_symbol(grp_begin, xn);
+#endif
+    for (unsigned long long grp = grp_begin; grp < grp_end; ++grp) {
         unsigned long long sym = grp * SPW + slot;
         const bool active = sym < p.n_sym;
         if (!active) sym = p.n_sym - 1;
 
-        // ---- pass 0: load (CP skipped, bit reversal folded into the index) ----
-        float2 x[E];
-        {
-            const float2* src = p.rx + sym * in_stride + p.cp + in_thread;
-            constexpr int GI = O::kGroupIn;
-            static_for<E / GI>([&](auto Q) {
-                constexpr int q = Q;   // butterfly register bits of pass 0 (low kR[0] register bits)
-                constexpr int idx0 = O::bitrev(O::reg_pos(0, q), LOG2N);
-                static_assert(GI == 1 || GI == 2, "plans load one or two adjacent samples per register group");
-                if constexpr (GI == 1) {
-                    x[q] = src[idx0];
-                } else if constexpr (GI == 2) {
-                    // register bit kR[0] is the group bit: adjacent input samples
-                    const float4 v = *reinterpret_cast<const float4*>(src + idx0);
-                    x[q] = make_float2(v.x, v.y);
-                    x[q | (1 << P::kR[0])] = make_float2(v.z, v.w);
-                }
-            });
-        }
+        // ---- pass 0 ----
+#ifdef SDR_PREFETCH
+        static_for<E>([&](auto M) { constexpr int m = M; x[m] = xn[m]; });
+        if (grp + 1 < grp_end) load_symbol(grp + 1, xn);   // in flight during this symbol's compute
+#else
+        load_symbol(grp, x);
+#endif
         static_for<P::kR[0]>([&](auto S) {
             constexpr int c = P::kC0[0] + S;
             constexpr int bi = O::bfly_bit(0, c);
@@ -366,7 +421,33 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) rx_fused_kernel(const RxP
                     const float w = wgt ? wgt[k + g] : p.w0;
                     idx[g] = demap_point<float, MI, MQ, true, FULL>(y.x, y.y, p.inorm, w, l + g * BPS);
                 });
-                if (p.llr && active) store_floats<GO * BPS>(p.llr + (bin0 + k) * BPS, l);
+                if constexpr (STAGE) {
+                    if (p.llr && active) {
+                        constexpr int VW = (CHUNK % 4 == 0) ? 4 : 2;            // floats per vector
+                        constexpr int VPL = CHUNK / VW;                          // vectors per lane
+                        const int lane = tid & 63;
+                        float* stg = reinterpret_cast<float*>(lds + STG_OFF + (tid >> 6) * STG_WAVE_BYTES);
+                        store_floats<CHUNK>(stg + lane * (STG_STRIDE / 4), l);
+                        __builtin_amdgcn_wave_barrier();
+                        constexpr int gbits = O::kLogE - P::kR[LAST];
+                        float* gbase = p.llr + (bin0 + O::reg_pos(LAST, h * GO) + ((tid & ~63) << gbits)) * BPS;
+                        static_for<VPL>([&](auto I) {
+                            constexpr int i = I;
+                            const int v = i * 64 + lane;
+                            const float* src = stg + (v / VPL) * (STG_STRIDE / 4) + (v % VPL) * VW;
+                            if constexpr (VW == 4) {
+                                const float4 q4 = *reinterpret_cast<const float4*>(src);
+                                stream_store4(gbase + v * 4, q4.x, q4.y, q4.z, q4.w);
+                            } else {
+                                const float2 q2 = *reinterpret_cast<const float2*>(src);
+                                stream_store2(gbase + v * 2, q2.x, q2.y);
+                            }
+                        });
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                } else {
+                    if (p.llr && active) store_floats<GO * BPS>(p.llr + (bin0 + k) * BPS, l);
+                }
                 if constexpr (FULL) {
                     if (p.hard) static_for<GO>([&](auto G) { constexpr int g = G; lds_idx[slot * N + k + g] = static_cast<unsigned char>(idx[g]); });
                     if (p.counters && active) {
@@ -443,11 +524,24 @@ int launch_rx_fused(sdr_ctx* ctx, const RxParams& p)
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, O::kWG, 0);
         if (e != hipSuccess) return fail_hip(e, "hipOccupancyMaxActiveBlocksPerMultiprocessor");
         blocks_per_cu = nb > 0 ? nb : 1;
+        if (getenv("SDR_DEBUG")) fprintf(stderr, "[sdr] rx_fused<%d,%d,%d,%d>: %d threads/WG, %d WG/CU, %d CUs\n", LOG2N, MI, MQ, int(FULL), O::kWG, blocks_per_cu, ctx->num_cu);
     }
     const unsigned long long n_groups = (p.n_sym + O::kSPW - 1) / O::kSPW;
-    unsigned long long blocks = static_cast<unsigned long long>(ctx->num_cu) * blocks_per_cu;
-    if (blocks > n_groups) blocks = n_groups;
-    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(O::kWG), 0, ctx->stream, p);
+    // Each workgroup takes a run of consecutive symbol groups.  Short runs (many workgroups, the
+    // hardware dispatcher balancing them) measured faster than a resident grid striding over the
+    // batch; the per-workgroup twiddle set-up is amortised over the run.
+    unsigned long long per_wg = 2;
+    if (const char* ov = getenv("SDR_GROUPS_PER_WG")) per_wg = static_cast<unsigned long long>(atol(ov));   // tuning knob; 0 = resident grid
+    if (per_wg == 0) {
+        const unsigned long long resident = static_cast<unsigned long long>(ctx->num_cu) * blocks_per_cu;
+        per_wg = (n_groups + resident - 1) / resident;
+    }
+    if (per_wg > 0xFFFFFFFFull) per_wg = 0xFFFFFFFFull;
+    unsigned long long blocks = (n_groups + per_wg - 1) / per_wg;
+    if (blocks > 0x7FFFFFFFull) return fail(SDR_ERR_UNSUPPORTED, "batch too large for one launch");
+    RxParams q = p;
+    q.groups_per_wg = static_cast<uint32_t>(per_wg);
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(O::kWG), 0, ctx->stream, q);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(e, "rx_fused_kernel launch");
     return SDR_OK;

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmark for tuning: times sdr_ofdm_demod_c32 / sdr_ofdm_rx_c32 on resident data.
+
+  python tools/kbench.py --cases 1024:4 1024:6 1024:0 4096:8 --symbols 262144 --steps 10
+
+case = n_fft:bps[:eq]   (bps 0 = FFT only / ofdm::rx batch; eq = per-subcarrier equaliser sets)
+Inputs are random complex noise (values do not change the instruction stream).
+"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", nargs="+", default=["1024:4", "1024:6"])
+    ap.add_argument("--symbols", type=int, default=0, help="symbols per case (default: ~8 GiB of input+output)")
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    args = ap.parse_args()
+    import torch
+    from sdr_amd.ops import Context
+    ctx = Context(0)
+    for case in args.cases:
+        parts = case.split(":")
+        n, bps = int(parts[0]), int(parts[1])
+        with_eq = len(parts) > 2 and parts[2] == "eq"
+        cp = n // 4
+        bytes_sym = 8 * n + (4 * n * bps if bps else 8 * n)
+        n_sym = args.symbols or max(1024, min(1 << 20, (8 << 30) // (bytes_sym + 8 * cp)))
+        g = torch.Generator(device="cuda").manual_seed(1)
+        rx = torch.randn((n_sym, (n + cp) * 2), dtype=torch.float32, device="cuda", generator=g).mul_(0.05).view(torch.complex64)
+        eq = wgt = None
+        per = 0
+        if with_eq:
+            per = 14
+            n_sets = (n_sym + per - 1) // per
+            eq = torch.randn((n_sets, n * 2), dtype=torch.float32, device="cuda", generator=g).view(torch.complex64)
+            wgt = torch.rand((n_sets, n), dtype=torch.float32, device="cuda", generator=g)
+        if bps:
+            out = torch.empty((n_sym, n, bps), dtype=torch.float32, device="cuda")
+            step = lambda: ctx.demod(rx, n, cp, bps, eq=eq, llr_weight=(wgt if wgt is not None else 1.5), sym_per_set=per, out_llr=out)
+        else:
+            step = lambda: ctx.ofdm_rx(rx, n, cp)
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.steps):
+            step()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / args.steps
+        gbs = bytes_sym * n_sym / ms / 1e6
+        print(f"case {case:>12s} n_sym {n_sym:8d}  {ms:8.3f} ms/launch  {n_sym / ms / 1e3:9.2f} Msym/s  {gbs:8.1f} GB/s  {gbs / 80:5.1f} % of 8 TB/s", flush=True)
+        del rx, eq, wgt
+        if bps:
+            del out
+        torch.cuda.empty_cache()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
