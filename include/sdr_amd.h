@@ -108,6 +108,9 @@ int sdr_from_constl_host_c32(sdr_ctx* ctx, int mod, const void* h_sym, size_t n_
 int sdr_from_constl_host_c64(sdr_ctx* ctx, int mod, const void* h_sym, size_t n_sym, uint8_t* h_bytes);
 /* nearest() per symbol: one uint16 index each. */
 int sdr_nearest_c32(sdr_ctx* ctx, int mod, const void* d_sym, size_t n_sym, uint16_t* d_index);
+int sdr_nearest_c64(sdr_ctx* ctx, int mod, const void* d_sym, size_t n_sym, uint16_t* d_index);
+int sdr_nearest_host_c32(sdr_ctx* ctx, int mod, const void* h_sym, size_t n_sym, uint16_t* h_index);
+int sdr_nearest_host_c64(sdr_ctx* ctx, int mod, const void* h_sym, size_t n_sym, uint16_t* h_index);
 /* Host-side description of a constellation: norm, inorm, 2^mod (I,Q) levels. */
 int sdr_constellation_f32(int mod, float* norm, float* inorm, float* table);
 
@@ -144,6 +147,9 @@ typedef struct sdr_demod_args {
     uint64_t* d_counters;
 } sdr_demod_args;
 int sdr_ofdm_demod_c32(sdr_ctx* ctx, const sdr_demod_args* args);
+/* Same with every pointer in HOST memory (copies in, runs, copies out, synchronises);
+ * n_sets = number of tap / weight sets behind d_eq / d_llr_weight (ignored when both are NULL). */
+int sdr_ofdm_demod_host_c32(sdr_ctx* ctx, const sdr_demod_args* host_args, size_t n_sets);
 
 /* Equaliser taps and LLR weights from a channel estimate H (n values):
  *   p = |H|^2, G = conj(H)/p, w = norm^2 * p * inv_n0. */
@@ -151,6 +157,7 @@ int sdr_zf_taps_c32(sdr_ctx* ctx, int mod, const void* d_chan, size_t n, float i
 
 /* Soft demapping alone (X2) on equalised symbols already in memory. */
 int sdr_soft_demap_c32(sdr_ctx* ctx, int mod, const void* d_sym, size_t n_sym, const float* d_weight, float weight0, float* d_llr);
+int sdr_soft_demap_host_c32(sdr_ctx* ctx, int mod, const void* h_sym, size_t n_sym, const float* h_weight, float weight0, float* h_llr);
 
 /* ---- X4: device frame generator, AWGN and Monte-Carlo link (no reference counterpart; model:
  * app/QFDemoWindow.cpp:201-224) --------------------------------------------------------------

@@ -102,10 +102,15 @@ SIGNATURES = {
     "sdr_from_constl_host_c32": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "sdr_from_constl_host_c64": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "sdr_nearest_c32": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "sdr_nearest_c64": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "sdr_nearest_host_c32": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "sdr_nearest_host_c64": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "sdr_constellation_f32": (c_int, [c_int, POINTER(c_float), POINTER(c_float), c_void_p]),
     "sdr_ofdm_demod_c32": (c_int, [c_void_p, POINTER(DemodArgs)]),
+    "sdr_ofdm_demod_host_c32": (c_int, [c_void_p, POINTER(DemodArgs), c_size_t]),
     "sdr_zf_taps_c32": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_float, c_void_p, c_void_p]),
     "sdr_soft_demap_c32": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p, c_float, c_void_p]),
+    "sdr_soft_demap_host_c32": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p, c_float, c_void_p]),
     "sdr_link_generate_c32": (c_int, [c_void_p, POINTER(LinkArgs)]),
     "sdr_link_ber_c32": (c_int, [c_void_p, POINTER(LinkArgs)]),
     "sdr_philox4x32_10": (c_int, [POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32)]),

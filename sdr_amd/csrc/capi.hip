@@ -158,8 +158,24 @@ int sdr_from_constl_host_c64(sdr_ctx* ctx, int mod, const void* h_sym, size_t n_
 int sdr_nearest_c32(sdr_ctx* ctx, int mod, const void* d_sym, size_t n_sym, uint16_t* d_index)
 {
     SDR_TRY(ensure_device(ctx));
-    return nearest_dev(ctx, mod, d_sym, n_sym, d_index);
+    return nearest_dev(ctx, false, mod, d_sym, n_sym, d_index);
 }
+int sdr_nearest_c64(sdr_ctx* ctx, int mod, const void* d_sym, size_t n_sym, uint16_t* d_index)
+{
+    SDR_TRY(ensure_device(ctx));
+    return nearest_dev(ctx, true, mod, d_sym, n_sym, d_index);
+}
+static int nearest_host(sdr_ctx* ctx, bool is_double, int mod, const void* h_sym, size_t n_sym, uint16_t* h_index)
+{
+    if (!valid_mod(mod)) return fail(SDR_ERR_INVALID, "unknown modulation %d", mod);
+    if (n_sym == 0) return SDR_OK;
+    if (!h_sym || !h_index) return fail(SDR_ERR_INVALID, "null host pointer");
+    const size_t in_bytes = n_sym * 2 * (is_double ? sizeof(double) : sizeof(float));
+    return with_host_buffers(ctx, h_sym, in_bytes, h_index, n_sym * sizeof(uint16_t), false,
+                             [&](void* d_in, void* d_out) { return nearest_dev(ctx, is_double, mod, d_in, n_sym, static_cast<uint16_t*>(d_out)); });
+}
+int sdr_nearest_host_c32(sdr_ctx* ctx, int mod, const void* h_sym, size_t n_sym, uint16_t* h_index) { return nearest_host(ctx, false, mod, h_sym, n_sym, h_index); }
+int sdr_nearest_host_c64(sdr_ctx* ctx, int mod, const void* h_sym, size_t n_sym, uint16_t* h_index) { return nearest_host(ctx, true, mod, h_sym, n_sym, h_index); }
 
 int sdr_constellation_f32(int mod, float* norm, float* inorm, float* table)
 {
@@ -206,6 +222,66 @@ int sdr_soft_demap_c32(sdr_ctx* ctx, int mod, const void* d_sym, size_t n_sym, c
 {
     SDR_TRY(ensure_device(ctx));
     return soft_demap_dev(ctx, mod, d_sym, n_sym, d_weight, weight0, d_llr);
+}
+
+// host-memory forms: explicit device scratch (hipMalloc/hipFree per call -- convenience path)
+namespace {
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) { if (!bytes) return SDR_OK; hipError_t e = hipMalloc(&p, bytes); return e == hipSuccess ? SDR_OK : fail_hip(e, "hipMalloc(host-form scratch)"); }
+};
+}
+
+int sdr_soft_demap_host_c32(sdr_ctx* ctx, int mod, const void* h_sym, size_t n_sym, const float* h_weight, float weight0, float* h_llr)
+{
+    SDR_TRY(ensure_device(ctx));
+    if (!valid_mod(mod)) return fail(SDR_ERR_INVALID, "unknown modulation %d", mod);
+    if (n_sym == 0) return SDR_OK;
+    if (!h_sym || !h_llr) return fail(SDR_ERR_INVALID, "null host pointer");
+    DevBuf sym, w, out;
+    SDR_TRY(sym.alloc(n_sym * 8));
+    SDR_TRY(out.alloc(n_sym * mod * 4));
+    if (h_weight) SDR_TRY(w.alloc(n_sym * 4));
+    SDR_HIP(hipMemcpyAsync(sym.p, h_sym, n_sym * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (h_weight) SDR_HIP(hipMemcpyAsync(w.p, h_weight, n_sym * 4, hipMemcpyHostToDevice, ctx->stream));
+    SDR_TRY(soft_demap_dev(ctx, mod, sym.p, n_sym, static_cast<const float*>(w.p), weight0, static_cast<float*>(out.p)));
+    SDR_HIP(hipMemcpyAsync(h_llr, out.p, n_sym * mod * 4, hipMemcpyDeviceToHost, ctx->stream));
+    SDR_HIP(hipStreamSynchronize(ctx->stream));
+    return SDR_OK;
+}
+
+int sdr_ofdm_demod_host_c32(sdr_ctx* ctx, const sdr_demod_args* host_args, size_t n_sets)
+{
+    SDR_TRY(ensure_device(ctx));
+    if (!host_args) return fail(SDR_ERR_INVALID, "null args");
+    if (host_args->struct_size != sizeof(sdr_demod_args)) return fail(SDR_ERR_INVALID, "sdr_demod_args.struct_size mismatch");
+    sdr_demod_args a = *host_args;
+    if (!valid_mod(static_cast<int>(a.mod))) return fail(SDR_ERR_INVALID, "unknown modulation %u", a.mod);
+    if (a.n_sym == 0 || a.n_fft == 0) return SDR_OK;
+    if (!is_pow2(a.n_fft)) return fail(SDR_ERR_NOT_POW2, "%s", kPow2Message);
+    if (!a.d_rx) return fail(SDR_ERR_INVALID, "null rx");
+    const size_t bins = size_t(a.n_sym) * a.n_fft;
+    const size_t rx_bytes = size_t(a.n_sym) * (size_t(a.n_fft) + a.cp) * 8;
+    const size_t hard_bytes = bins * a.mod / 8;
+    DevBuf rx, eq, wgt, llr, hard, fft, ref, cnt;
+    SDR_TRY(rx.alloc(rx_bytes));
+    SDR_HIP(hipMemcpyAsync(rx.p, a.d_rx, rx_bytes, hipMemcpyHostToDevice, ctx->stream));
+    a.d_rx = rx.p;
+    if (a.d_eq) { SDR_TRY(eq.alloc(n_sets * a.n_fft * 8)); SDR_HIP(hipMemcpyAsync(eq.p, a.d_eq, n_sets * a.n_fft * 8, hipMemcpyHostToDevice, ctx->stream)); a.d_eq = eq.p; }
+    if (a.d_llr_weight) { SDR_TRY(wgt.alloc(n_sets * a.n_fft * 4)); SDR_HIP(hipMemcpyAsync(wgt.p, a.d_llr_weight, n_sets * a.n_fft * 4, hipMemcpyHostToDevice, ctx->stream)); a.d_llr_weight = static_cast<const float*>(wgt.p); }
+    if (a.d_ref_hard) { SDR_TRY(ref.alloc(hard_bytes)); SDR_HIP(hipMemcpyAsync(ref.p, a.d_ref_hard, hard_bytes, hipMemcpyHostToDevice, ctx->stream)); a.d_ref_hard = static_cast<const uint8_t*>(ref.p); }
+    if (a.d_counters) { SDR_TRY(cnt.alloc(64)); SDR_HIP(hipMemcpyAsync(cnt.p, a.d_counters, 64, hipMemcpyHostToDevice, ctx->stream)); a.d_counters = static_cast<uint64_t*>(cnt.p); }
+    if (a.d_llr) { SDR_TRY(llr.alloc(bins * a.mod * 4)); a.d_llr = static_cast<float*>(llr.p); }
+    if (a.d_hard) { SDR_TRY(hard.alloc(hard_bytes)); a.d_hard = static_cast<uint8_t*>(hard.p); }
+    if (a.d_fft) { SDR_TRY(fft.alloc(bins * 8)); a.d_fft = fft.p; }
+    SDR_TRY(sdr_ofdm_demod_c32(ctx, &a));
+    if (host_args->d_llr) SDR_HIP(hipMemcpyAsync(host_args->d_llr, llr.p, bins * a.mod * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (host_args->d_hard) SDR_HIP(hipMemcpyAsync(host_args->d_hard, hard.p, hard_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (host_args->d_fft) SDR_HIP(hipMemcpyAsync(host_args->d_fft, fft.p, bins * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (host_args->d_counters) SDR_HIP(hipMemcpyAsync(host_args->d_counters, cnt.p, 64, hipMemcpyDeviceToHost, ctx->stream));
+    SDR_HIP(hipStreamSynchronize(ctx->stream));
+    return SDR_OK;
 }
 
 int sdr_link_generate_c32(sdr_ctx* ctx, const sdr_link_args* args)

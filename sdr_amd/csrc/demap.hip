@@ -199,12 +199,12 @@ static int launch_nearest(sdr_ctx* ctx, bool is_double, int mod, const void* d_s
     return SDR_OK;
 }
 
-int nearest_dev(sdr_ctx* ctx, int mod, const void* d_sym, size_t n_sym, uint16_t* d_index)
+int nearest_dev(sdr_ctx* ctx, bool is_double, int mod, const void* d_sym, size_t n_sym, uint16_t* d_index)
 {
     if (!valid_mod(mod)) return fail(SDR_ERR_INVALID, "unknown modulation %d", mod);
     if (n_sym == 0) return SDR_OK;
     if (!d_sym || !d_index) return fail(SDR_ERR_INVALID, "null device pointer");
-    return launch_nearest(ctx, false, mod, d_sym, n_sym, d_index);
+    return launch_nearest(ctx, is_double, mod, d_sym, n_sym, d_index);
 }
 
 int from_constl_dev(sdr_ctx* ctx, bool is_double, int mod, const void* d_sym, size_t n_sym, uint8_t* d_bytes)

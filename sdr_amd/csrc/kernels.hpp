@@ -14,7 +14,7 @@ int fft_generic_f64(sdr_ctx* ctx, const void* d_in, void* d_out, size_t n, bool 
 // demap.hip: element-wise constellation kernels.
 int to_constl_dev(sdr_ctx* ctx, bool is_double, int mod, const uint8_t* d_bytes, size_t n_sym, void* d_out);
 int from_constl_dev(sdr_ctx* ctx, bool is_double, int mod, const void* d_sym, size_t n_sym, uint8_t* d_bytes);
-int nearest_dev(sdr_ctx* ctx, int mod, const void* d_sym, size_t n_sym, uint16_t* d_index);
+int nearest_dev(sdr_ctx* ctx, bool is_double, int mod, const void* d_sym, size_t n_sym, uint16_t* d_index);
 int soft_demap_dev(sdr_ctx* ctx, int mod, const void* d_sym, size_t n_sym, const float* d_weight, float weight0, float* d_llr);
 int zf_taps_dev(sdr_ctx* ctx, int mod, const void* d_chan, size_t n, float inv_n0, void* d_taps, float* d_weight);
 // equalise + LLR + hard + counters on FFT outputs already in memory (generic sizes of the fused path)
