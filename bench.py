@@ -32,6 +32,18 @@ WORKLOADS = {
 }
 
 
+def measured_traffic(workload, n_sym):
+    """HBM bytes per launch from the committed PMC passes (profiles/r1_traffic.json: FETCH_SIZE and
+    WRITE_SIZE collected in separate rocprofv3 runs of this script, gfx950 correction applied);
+    None when no pass exists for the workload."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as f:
+            k = json.load(f)["kernels"].get(workload)
+        return None if k is None else k["hbm_bytes_per_symbol"] * n_sym
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def algorithmic_bytes_per_symbol(n_fft, bps):
     """payload samples read (CP skipped) + fp32 LLR written."""
     return 8 * n_fft + 4 * n_fft * bps
@@ -126,7 +138,8 @@ def time_workload(ctx, torch, dist, name, steps, warmup, world, rank, n_sym_over
         "n_fft": n_fft, "cp": cp, "bps": bps, "n_sym": n_sym, "elapsed": elapsed,
         "sym_per_s": world * n_sym * steps / elapsed,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "bytes_per_symbol": b_sym, "symbols_per_launch": n_sym, "avg_launch_ms": avg_launch_s * 1e3},
+                     "traffic": measured_traffic(name, n_sym), "traffic_unit": "bytes per launch (rocprofv3 PMC, separate passes; profiles/r1_traffic.json)",
+                     "algorithmic_bytes_per_launch": b_sym * n_sym, "bytes_per_symbol": b_sym, "symbols_per_launch": n_sym, "avg_launch_ms": avg_launch_s * 1e3},
     }
     del rx, llr, eq, wgt
     torch.cuda.empty_cache()
