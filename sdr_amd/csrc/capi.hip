@@ -42,6 +42,8 @@ int ofdm_tx_device(sdr_ctx* ctx, bool is_double, const void* d_in, size_t n_fft,
     if (cp > n_fft) return fail(SDR_ERR_INVALID, "batched tx needs cp (%zu) <= n_fft (%zu)", cp, n_fft);
     if (n_fft == 0) return SDR_OK;
     if (!d_in || !d_out) return fail(SDR_ERR_INVALID, "null device pointer");
+    if (!is_double && tx_fused_ok(n_fft, cp, d_in, d_out))
+        return tx_fused_launch(ctx, d_in, static_cast<uint32_t>(n_fft), static_cast<uint32_t>(cp), n_sym, d_out);
     return is_double ? fft_generic_f64(ctx, d_in, d_out, n_fft, true, n_fft, 0, n_fft + cp, cp, cp, n_sym)
                      : fft_generic_f32(ctx, d_in, d_out, n_fft, true, n_fft, 0, n_fft + cp, cp, cp, n_sym);
 }

@@ -29,5 +29,7 @@ int rx_fft_only_launch(sdr_ctx* ctx, const void* d_in, uint32_t n_fft, uint32_t 
 // link.hip: frame generator, AWGN, Monte-Carlo link.
 int link_generate(sdr_ctx* ctx, const sdr_link_args& a);
 int link_ber(sdr_ctx* ctx, const sdr_link_args& a);
+bool tx_fused_ok(size_t n_fft, size_t cp, const void* d_in, const void* d_out);
+int tx_fused_launch(sdr_ctx* ctx, const void* d_in, uint32_t n_fft, uint32_t cp, uint64_t n_sym, void* d_out);
 
 } // namespace sdr

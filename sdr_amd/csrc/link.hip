@@ -9,12 +9,49 @@
 #include "kernels.hpp"
 #include "qam.hpp"
 #include "rng.hpp"
+#include "link_fused.hpp"
 
 #include <cmath>
+#include <cstdlib>
 
 namespace sdr {
 
+#define SDR_DECL_LINK(L) \
+    int tx_fused_dispatch_##L(sdr_ctx*, const TxParams&, int); \
+    int mc_fused_dispatch_##L(sdr_ctx*, const McParams&, int);
+SDR_DECL_LINK(6) SDR_DECL_LINK(7) SDR_DECL_LINK(8) SDR_DECL_LINK(9) SDR_DECL_LINK(10) SDR_DECL_LINK(11) SDR_DECL_LINK(12)
+#undef SDR_DECL_LINK
+
 namespace {
+
+int tx_dispatch(sdr_ctx* ctx, unsigned log2n, const TxParams& p, int mod)
+{
+    switch (log2n) {
+        case 6: return tx_fused_dispatch_6(ctx, p, mod);
+        case 7: return tx_fused_dispatch_7(ctx, p, mod);
+        case 8: return tx_fused_dispatch_8(ctx, p, mod);
+        case 9: return tx_fused_dispatch_9(ctx, p, mod);
+        case 10: return tx_fused_dispatch_10(ctx, p, mod);
+        case 11: return tx_fused_dispatch_11(ctx, p, mod);
+        case 12: return tx_fused_dispatch_12(ctx, p, mod);
+        default: return fail(SDR_ERR_UNSUPPORTED, "n_fft = 2^%u has no fused kernel", log2n);
+    }
+}
+int mc_dispatch(sdr_ctx* ctx, unsigned log2n, const McParams& p, int mod)
+{
+    switch (log2n) {
+        case 6: return mc_fused_dispatch_6(ctx, p, mod);
+        case 7: return mc_fused_dispatch_7(ctx, p, mod);
+        case 8: return mc_fused_dispatch_8(ctx, p, mod);
+        case 9: return mc_fused_dispatch_9(ctx, p, mod);
+        case 10: return mc_fused_dispatch_10(ctx, p, mod);
+        case 11: return mc_fused_dispatch_11(ctx, p, mod);
+        case 12: return mc_fused_dispatch_12(ctx, p, mod);
+        default: return fail(SDR_ERR_UNSUPPORTED, "n_fft = 2^%u has no fused kernel", log2n);
+    }
+}
+bool is_aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+bool generic_only() { static const bool v = getenv("SDR_GENERIC_LINK") != nullptr; return v; }   // test/tuning knob
 
 constexpr unsigned kThreads = 256;
 
@@ -107,6 +144,19 @@ int link_generate(sdr_ctx* ctx, const sdr_link_args& a)
     SDR_TRY(check_link(a));
     if (a.n_sym == 0) return SDR_OK;
     if (!a.d_rx) return fail(SDR_ERR_INVALID, "null d_rx");
+    if (!generic_only() && rx_fused_supported(a.n_fft, a.mod) && is_aligned(a.d_rx, 8) && is_aligned(a.d_tx_bits, 4) && is_aligned(a.d_chan, 8)) {
+        const void* tw = nullptr;
+        SDR_TRY(get_twiddles(ctx, a.n_fft, true, false, &tw));
+        TxParams p = {};
+        p.tw_inv = static_cast<const float2*>(tw);
+        p.chan = static_cast<const float2*>(a.d_chan);
+        p.out = static_cast<float2*>(a.d_rx);
+        p.tx_bits = a.d_tx_bits;
+        p.n_sym = a.n_sym; p.seed = a.seed; p.first_symbol = a.first_symbol;
+        p.cp = a.cp; p.sym_per_set = a.sym_per_set; p.sigma = a.sigma;
+        p.norm = 1.0f / std::sqrt(static_cast<float>(grid_energy(static_cast<int>(a.mod))));
+        return tx_dispatch(ctx, ilog2(a.n_fft), p, static_cast<int>(a.mod));
+    }
     const size_t total = size_t(a.n_sym) * a.n_fft;
     void* freq = nullptr;
     void* idx = nullptr;
@@ -133,6 +183,24 @@ int link_generate(sdr_ctx* ctx, const sdr_link_args& a)
     return SDR_OK;
 }
 
+// Batched ofdm::tx for the tuned sizes (bins in device memory -> samples with cyclic prefix).
+bool tx_fused_ok(size_t n_fft, size_t cp, const void* d_in, const void* d_out)
+{
+    return n_fft <= 4096 && rx_fused_supported(static_cast<uint32_t>(n_fft), 0) && cp <= n_fft && is_aligned(d_in, 16) && is_aligned(d_out, 8);
+}
+int tx_fused_launch(sdr_ctx* ctx, const void* d_in, uint32_t n_fft, uint32_t cp, uint64_t n_sym, void* d_out)
+{
+    const void* tw = nullptr;
+    SDR_TRY(get_twiddles(ctx, n_fft, true, false, &tw));
+    TxParams p = {};
+    p.freq = static_cast<const float2*>(d_in);
+    p.tw_inv = static_cast<const float2*>(tw);
+    p.out = static_cast<float2*>(d_out);
+    p.n_sym = n_sym;
+    p.cp = cp;
+    return tx_dispatch(ctx, ilog2(n_fft), p, 0);
+}
+
 // Monte-Carlo link: symbols are produced and consumed chunk by chunk in device scratch; only
 // the eight counters are outputs.  (Tuned sizes use the fully fused kernel in rx_fused.hip.)
 int link_ber(sdr_ctx* ctx, const sdr_link_args& a)
@@ -140,6 +208,22 @@ int link_ber(sdr_ctx* ctx, const sdr_link_args& a)
     SDR_TRY(check_link(a));
     if (!a.d_counters) return fail(SDR_ERR_INVALID, "null d_counters");
     if (a.n_sym == 0) return SDR_OK;
+    if (!generic_only() && rx_fused_supported(a.n_fft, a.mod)) {
+        const void* twf = nullptr;
+        const void* twi = nullptr;
+        SDR_TRY(get_twiddles(ctx, a.n_fft, false, false, &twf));
+        SDR_TRY(get_twiddles(ctx, a.n_fft, true, false, &twi));
+        McParams p = {};
+        p.tw_fwd = static_cast<const float2*>(twf);
+        p.tw_inv = static_cast<const float2*>(twi);
+        p.counters = reinterpret_cast<unsigned long long*>(a.d_counters);
+        p.n_sym = a.n_sym; p.seed = a.seed; p.first_symbol = a.first_symbol;
+        p.sigma = a.sigma; p.w0 = a.llr_weight0;
+        const float e = static_cast<float>(grid_energy(static_cast<int>(a.mod)));
+        p.norm = 1.0f / std::sqrt(e);
+        p.inorm = std::sqrt(e);
+        return mc_dispatch(ctx, ilog2(a.n_fft), p, static_cast<int>(a.mod));
+    }
     const size_t sym_bytes = (size_t(a.n_fft) + a.cp) * sizeof(float2);
     size_t chunk = (size_t(256) << 20) / sym_bytes;
     if (chunk == 0) chunk = 1;

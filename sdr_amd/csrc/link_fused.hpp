@@ -1,0 +1,362 @@
+// link_fused.hpp -- tuned transmit-side and Monte-Carlo kernels for n_fft = 64..4096 (fp32).
+//
+//   tx_fused_kernel   ofdm::tx for a batch (lib/inc/ofdm.hpp:13-24: IFFT with the reference
+//                     network, /N, cyclic prefix), optionally fed by the Philox index generator +
+//                     to_constl (lib/inc/modulation.hpp:78-94) + channel, and optionally followed
+//                     by AWGN: the device frame generator.
+//   mc_fused_kernel   generate -> IFFT -> + noise -> FFT -> demap -> count, one symbol per
+//                     workgroup pass, nothing but eight counters ever written to HBM
+//                     (model: app/QFDemoWindow.cpp:201-224 with a channel inserted).
+// Same plans, same exchange layouts and the same operation DAG as rx_fused.hpp; the inverse
+// transform only swaps the twiddle table (theta sign, lib/inc/fft.hpp:114) and divides by N
+// (:200-202).  Definitions of the generator (no reference counterpart) are in rng.hpp/DESIGN.md.
+#pragma once
+
+#include "rng.hpp"
+#include "rx_fused.hpp"
+
+namespace sdr {
+
+struct TxParams {
+    const float2* freq;          // n_sym x N bins (SRC_GLOBAL) or null
+    const float2* tw_inv;        // N-1 inverse twiddles
+    const float2* chan;          // n_sets x N or null (generator only)
+    float2* out;                 // n_sym x (N + cp)
+    uint8_t* tx_bits;            // packed transmitted bits or null (generator only)
+    unsigned long long n_sym;
+    unsigned long long seed;
+    unsigned long long first_symbol;
+    uint32_t cp;
+    uint32_t sym_per_set;
+    float sigma;                 // 0 with NOISE = false
+    float norm;
+    uint32_t groups_per_wg;
+};
+
+struct McParams {
+    const float2* tw_fwd;
+    const float2* tw_inv;
+    unsigned long long* counters;
+    unsigned long long n_sym;
+    unsigned long long seed;
+    unsigned long long first_symbol;
+    float sigma;
+    float w0;
+    float norm;
+    float inorm;
+    uint32_t groups_per_wg;
+};
+
+// integer grid level of Gray code g on an axis with M bits, as float
+template <int M>
+__device__ __forceinline__ float level_of(unsigned g)
+{
+    if constexpr (M == 0) return 0.0f;
+    const unsigned b = g ^ (g >> 1) ^ (g >> 2) ^ (g >> 3) ^ (g >> 4);
+    return static_cast<float>(2 * static_cast<int>(b & ((1u << M) - 1u)) - ((1 << M) - 1));
+}
+
+// Transmitted indices of the E elements a thread holds, sharing Philox blocks: element index
+// i = IDX(m) | thread_part; block = i mod (N/8), 16-bit lane = i / (N/8) = the top three index
+// bits, which are register bits in both the first-pass input pattern and the last-pass output
+// pattern of every plan (their butterfly bits are the top >= 3 bits).
+template <int LOG2N, bool OUTPUT_SIDE>
+struct TxIndexMap {
+    using O = PlanOps<LOG2N>;
+    using A = FftAddr<LOG2N>;
+    static constexpr int kStrideLog = LOG2N - 3;
+    static constexpr int idx_of(int m) { return OUTPUT_SIDE ? A::out_reg(m) : A::in_reg(m); }
+    static constexpr int lane_mask()   // register bits that carry index bits >= kStrideLog
+    {
+        int mk = 0;
+        for (int i = 0; i < O::kLogE; ++i)
+            if (idx_of(1 << i) >> kStrideLog) mk |= 1 << i;
+        return mk;
+    }
+};
+
+template <int LOG2N, int BPS, bool OUTPUT_SIDE, typename F>
+__device__ __forceinline__ void for_each_tx_index(unsigned long long seed, unsigned long long g, int thread_part, F&& f)
+{
+    using O = PlanOps<LOG2N>;
+    using T = TxIndexMap<LOG2N, OUTPUT_SIDE>;
+    constexpr int E = O::kE;
+    constexpr int lane_mask = T::lane_mask();
+    static_assert(O::popcount(lane_mask) == 3, "the top three index bits must be register bits");
+    constexpr int rest_mask = (E - 1) & ~lane_mask;
+    static_for<E / 8>([&](auto J) {
+        constexpr int mrest = O::pdep(J, rest_mask);
+        const uint32_t block = static_cast<uint32_t>((T::idx_of(mrest) | thread_part) & ((1 << T::kStrideLog) - 1));
+        const Philox4 r = tx_block(seed, g, block);
+        static_for<8>([&](auto L) {
+            constexpr int m = mrest | O::pdep(L, lane_mask);
+            constexpr uint32_t lane = static_cast<uint32_t>(T::idx_of(m) >> T::kStrideLog);
+            const uint32_t word = r.v[lane >> 1];
+            f(std::integral_constant<int, m>{}, ((word >> (16u * (lane & 1u))) & 0xFFFFu) & ((1u << BPS) - 1u));
+        });
+    });
+}
+
+// MI + MQ == 0 with SRC_GLOBAL: plain batched ofdm::tx.  SRC_GLOBAL = false: Philox generator.
+template <int LOG2N, int MI, int MQ, bool SRC_GLOBAL, bool NOISE>
+__global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) tx_fused_kernel(const TxParams p)
+{
+    using O = PlanOps<LOG2N>;
+    using P = typename O::P;
+    using A = FftAddr<LOG2N>;
+    constexpr int N = O::kN, E = O::kE, TPS = O::kTPS, SPW = O::kSPW, LAST = O::kLast;
+    constexpr int BPS = MI + MQ;
+    constexpr int SYM_BYTES = O::max_sym_bytes();
+    constexpr int DATA_BYTES = SYM_BYTES * SPW;
+    constexpr int TW_BYTES = O::kMidCount * 8;
+    constexpr int IDX_BYTES = SRC_GLOBAL ? 0 : N * SPW;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[DATA_BYTES + TW_BYTES + IDX_BYTES + 16];
+    unsigned char* lds_idx = lds + DATA_BYTES + TW_BYTES;
+
+    const int tid = threadIdx.x;
+    const int slot = tid / TPS;
+    const int t = tid % TPS;
+    A addr;
+    addr.init(t, slot, SYM_BYTES);
+    FftTwiddles<LOG2N> tw;
+    tw.init(p.tw_inv, reinterpret_cast<float2*>(lds + DATA_BYTES), tid, addr);
+    if constexpr (O::kMidCount > 0) __syncthreads();
+
+    const unsigned long long n_groups = (p.n_sym + SPW - 1) / SPW;
+    const unsigned long long grp_begin = static_cast<unsigned long long>(blockIdx.x) * p.groups_per_wg;
+    const unsigned long long grp_end = (grp_begin + p.groups_per_wg < n_groups) ? grp_begin + p.groups_per_wg : n_groups;
+    const size_t out_stride = static_cast<size_t>(N) + p.cp;
+    const unsigned long long first_set = p.sym_per_set ? p.first_symbol / p.sym_per_set : 0;
+
+    for (unsigned long long grp = grp_begin; grp < grp_end; ++grp) {
+        unsigned long long sym = grp * SPW + slot;
+        const bool active = sym < p.n_sym;
+        if (!active) sym = p.n_sym - 1;
+        const unsigned long long g = p.first_symbol + sym;
+
+        float2 x[E];
+        if constexpr (SRC_GLOBAL) {
+            const float2* src = p.freq + sym * N + addr.in_thread;
+            constexpr int GI = O::kGroupIn;
+            static_for<E / GI>([&](auto Q) {
+                constexpr int q = Q;
+                constexpr int idx0 = A::in_reg(q);
+                if constexpr (GI == 1) {
+                    x[q] = src[idx0];
+                } else {
+                    const float4 v = *reinterpret_cast<const float4*>(src + idx0);
+                    x[q] = make_float2(v.x, v.y);
+                    x[q | (1 << P::kR[0])] = make_float2(v.z, v.w);
+                }
+            });
+        } else {
+            const float2* chan = nullptr;
+            if (p.chan) {
+                const size_t set = p.sym_per_set ? static_cast<size_t>(g / p.sym_per_set - first_set) : 0;
+                chan = p.chan + set * N;
+            }
+            for_each_tx_index<LOG2N, BPS, false>(p.seed, g, addr.in_thread, [&](auto M, uint32_t idx) {
+                constexpr int m = M;
+                float xr = level_of<MI>(idx >> MQ) * p.norm;                 // table[idx] * norm (modulation.hpp:90-91)
+                float xi = level_of<MQ>(idx & ((1u << MQ) - 1u)) * p.norm;
+                const int i = A::in_reg(m) | addr.in_thread;
+                if (chan) {
+                    const float2 h = chan[i];
+                    const float tr = xr * h.x - xi * h.y;
+                    const float ti = xr * h.y + xi * h.x;
+                    xr = tr; xi = ti;
+                }
+                x[m] = make_float2(xr, xi);
+                if (p.tx_bits) lds_idx[slot * N + i] = static_cast<unsigned char>(idx);
+            });
+        }
+
+        fft_run<LOG2N>(x, lds, addr, tw);
+
+        // ---- /N (fft.hpp:200-202), noise, store with cyclic prefix (ofdm.hpp:21) ----
+        constexpr float LEN = static_cast<float>(N);
+        float2* dst = p.out + sym * out_stride;
+        const uint32_t cp = p.cp;
+        static_for<E>([&](auto M) {
+            constexpr int m = M;
+            const int n = A::out_reg(m) | addr.pos_last;
+            float2 v = make_float2(x[m].x / LEN, x[m].y / LEN);
+            float2 vcp = v;
+            if constexpr (NOISE) {
+                // samples n and n + N/2 share one Philox block; the top index bit is a register bit
+                constexpr int top = A::out_reg(m) >> (LOG2N - 1);
+                const Philox4 b = noise_block(p.seed, g, static_cast<uint32_t>(n & (N / 2 - 1)));
+                const float2 nz = gaussian_pair(top ? b.v[2] : b.v[0], top ? b.v[3] : b.v[1], p.sigma);
+                v.x = v.x + nz.x;
+                v.y = v.y + nz.y;
+            }
+            if (active) {
+                dst[cp + n] = v;
+                if (n + static_cast<int>(cp) >= N) {
+                    const uint32_t c = static_cast<uint32_t>(n) + cp - N;
+                    if constexpr (NOISE) {
+                        const float2 nz = cp_noise(p.seed, g, c, p.sigma);
+                        vcp.x = vcp.x + nz.x;
+                        vcp.y = vcp.y + nz.y;
+                    }
+                    dst[c] = vcp;
+                }
+            }
+        });
+        if constexpr (!SRC_GLOBAL) {
+            if (p.tx_bits) {
+                __syncthreads();
+                constexpr int WORDS = N * BPS / 32;
+                constexpr int CNT = (32 + BPS - 1) / BPS + 1;
+                if (active) {
+                    uint32_t* out = reinterpret_cast<uint32_t*>(p.tx_bits + static_cast<size_t>(sym) * N * BPS / 8);
+                    for (int j = t; j < WORDS; j += TPS) {
+                        const int k0 = (32 * j) / BPS;
+                        const int off = 32 * j - k0 * BPS;
+                        unsigned long long acc = 0;
+#pragma unroll
+                        for (int i = 0; i < CNT; ++i) {
+                            const int kk = (k0 + i < N) ? k0 + i : N - 1;
+                            acc = (acc << BPS) | lds_idx[slot * N + kk];
+                        }
+                        out[j] = __builtin_bswap32(static_cast<uint32_t>(acc >> (CNT * BPS - off - 32)));
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int LOG2N, int MI, int MQ>
+__global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) mc_fused_kernel(const McParams p)
+{
+    using O = PlanOps<LOG2N>;
+    using P = typename O::P;
+    using A = FftAddr<LOG2N>;
+    constexpr int N = O::kN, E = O::kE, TPS = O::kTPS, SPW = O::kSPW;
+    constexpr int BPS = MI + MQ;
+    constexpr int SYM_BYTES = O::max_sym_bytes();
+    constexpr int DATA_BYTES = SYM_BYTES * SPW;
+    constexpr int TW_BYTES = O::kMidCount * 8;
+    constexpr int TIME_BYTES = N * 8 * SPW;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[DATA_BYTES + 2 * TW_BYTES + TIME_BYTES + 16];
+    float2* lds_time = reinterpret_cast<float2*>(lds + DATA_BYTES + 2 * TW_BYTES);
+
+    const int tid = threadIdx.x;
+    const int slot = tid / TPS;
+    const int t = tid % TPS;
+    A addr;
+    addr.init(t, slot, SYM_BYTES);
+    FftTwiddles<LOG2N> tw_inv, tw_fwd;
+    tw_inv.init(p.tw_inv, reinterpret_cast<float2*>(lds + DATA_BYTES), tid, addr);
+    tw_fwd.init(p.tw_fwd, reinterpret_cast<float2*>(lds + DATA_BYTES + TW_BYTES), tid, addr);
+    if constexpr (O::kMidCount > 0) __syncthreads();
+
+    unsigned long long c_bit = 0, c_sym = 0, c_abs = 0, c_sign = 0, c_n = 0;
+    const unsigned long long n_groups = (p.n_sym + SPW - 1) / SPW;
+    const unsigned long long grp_begin = static_cast<unsigned long long>(blockIdx.x) * p.groups_per_wg;
+    const unsigned long long grp_end = (grp_begin + p.groups_per_wg < n_groups) ? grp_begin + p.groups_per_wg : n_groups;
+
+    for (unsigned long long grp = grp_begin; grp < grp_end; ++grp) {
+        unsigned long long sym = grp * SPW + slot;
+        const bool active = sym < p.n_sym;
+        if (!active) sym = p.n_sym - 1;
+        const unsigned long long g = p.first_symbol + sym;
+
+        // ---- transmit: indices -> constellation -> IFFT -> /N -> + noise ----
+        float2 x[E];
+        for_each_tx_index<LOG2N, BPS, false>(p.seed, g, addr.in_thread, [&](auto M, uint32_t idx) {
+            constexpr int m = M;
+            x[m] = make_float2(level_of<MI>(idx >> MQ) * p.norm, level_of<MQ>(idx & ((1u << MQ) - 1u)) * p.norm);
+        });
+        fft_run<LOG2N>(x, lds, addr, tw_inv);
+        constexpr float LEN = static_cast<float>(N);
+        static_for<E>([&](auto M) {
+            constexpr int m = M;
+            const int n = A::out_reg(m) | addr.pos_last;
+            constexpr int top = A::out_reg(m) >> (LOG2N - 1);
+            const Philox4 b = noise_block(p.seed, g, static_cast<uint32_t>(n & (N / 2 - 1)));
+            const float2 nz = gaussian_pair(top ? b.v[2] : b.v[0], top ? b.v[3] : b.v[1], p.sigma);
+            lds_time[slot * N + n] = make_float2(x[m].x / LEN + nz.x, x[m].y / LEN + nz.y);
+        });
+        __syncthreads();
+        // ---- receive: the CP would be dropped here (ofdm.hpp:41); its samples are never made ----
+        static_for<E>([&](auto M) { constexpr int m = M; x[m] = lds_time[slot * N + (A::in_reg(m) | addr.in_thread)]; });
+        fft_run<LOG2N>(x, lds, addr, tw_fwd);
+
+        for_each_tx_index<LOG2N, BPS, true>(p.seed, g, addr.pos_last, [&](auto M, uint32_t ref) {
+            constexpr int m = M;
+            float l[BPS];
+            const unsigned idx = demap_point<float, MI, MQ, true, true>(x[m].x, x[m].y, p.inorm, p.w0, l);
+            if (active) {
+                const unsigned diff = ref ^ idx;
+                c_bit += __popc(diff);
+                c_sym += (diff != 0);
+                c_n += 1;
+                static_for<BPS>([&](auto B) {
+                    constexpr int b = B;
+                    float a = fabsf(l[b]) * 1024.0f;
+                    a = (a < 1073741824.0f) ? a : 1073741824.0f;
+                    c_abs += static_cast<unsigned long long>(static_cast<long long>(a));
+                    c_sign += (((ref >> (BPS - 1 - b)) & 1u) != (l[b] < 0.0f ? 1u : 0u));
+                });
+            }
+        });
+        __syncthreads();
+    }
+
+    c_bit = wave_sum_u64(c_bit); c_sym = wave_sum_u64(c_sym); c_abs = wave_sum_u64(c_abs);
+    c_sign = wave_sum_u64(c_sign); c_n = wave_sum_u64(c_n);
+    if ((tid & 63) == 0) {
+        atomicAdd(&p.counters[0], c_bit);
+        atomicAdd(&p.counters[1], c_n * BPS);
+        atomicAdd(&p.counters[2], c_sym);
+        atomicAdd(&p.counters[3], c_n);
+        atomicAdd(&p.counters[5], c_abs);
+        atomicAdd(&p.counters[6], c_sign);
+    }
+    if (blockIdx.x == 0 && tid == 0) atomicAdd(&p.counters[4], p.n_sym);
+}
+
+inline unsigned long long resident_groups_per_wg(sdr_ctx* ctx, unsigned long long n_groups, int wg_per_cu)
+{
+    const unsigned long long resident = static_cast<unsigned long long>(ctx->num_cu) * static_cast<unsigned long long>(wg_per_cu > 0 ? wg_per_cu : 1);
+    unsigned long long per = (n_groups + resident - 1) / resident;
+    return per ? per : 1;
+}
+
+template <int LOG2N, int MI, int MQ, bool SRC_GLOBAL, bool NOISE>
+int launch_tx_fused(sdr_ctx* ctx, const TxParams& p)
+{
+    using O = PlanOps<LOG2N>;
+    const unsigned long long n_groups = (p.n_sym + O::kSPW - 1) / O::kSPW;
+    unsigned long long per_wg = 2;
+    const unsigned long long blocks = (n_groups + per_wg - 1) / per_wg;
+    if (blocks > 0x7FFFFFFFull) return fail(SDR_ERR_UNSUPPORTED, "batch too large for one launch");
+    TxParams q = p;
+    q.groups_per_wg = static_cast<uint32_t>(per_wg);
+    hipLaunchKernelGGL((tx_fused_kernel<LOG2N, MI, MQ, SRC_GLOBAL, NOISE>), dim3(static_cast<unsigned>(blocks)), dim3(O::kWG), 0, ctx->stream, q);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, "tx_fused_kernel launch");
+    return SDR_OK;
+}
+
+template <int LOG2N, int MI, int MQ>
+int launch_mc_fused(sdr_ctx* ctx, const McParams& p)
+{
+    using O = PlanOps<LOG2N>;
+    const unsigned long long n_groups = (p.n_sym + O::kSPW - 1) / O::kSPW;
+    // compute bound and atomics at the end of every workgroup: a resident grid with long runs
+    unsigned long long per_wg = resident_groups_per_wg(ctx, n_groups, 8);
+    if (per_wg < 4) per_wg = n_groups < 4 ? n_groups : 4;
+    const unsigned long long blocks = (n_groups + per_wg - 1) / per_wg;
+    McParams q = p;
+    q.groups_per_wg = static_cast<uint32_t>(per_wg > 0xFFFFFFFFull ? 0xFFFFFFFFull : per_wg);
+    hipLaunchKernelGGL((mc_fused_kernel<LOG2N, MI, MQ>), dim3(static_cast<unsigned>(blocks)), dim3(O::kWG), 0, ctx->stream, q);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, "mc_fused_kernel launch");
+    return SDR_OK;
+}
+
+} // namespace sdr

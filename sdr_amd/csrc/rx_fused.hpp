@@ -186,6 +186,119 @@ __device__ __forceinline__ void store_floats(float* __restrict__ dst, const floa
     }
 }
 
+
+// Per-thread state of one plan: LDS addresses of both exchanges and the index parts contributed
+// by the thread bits.  Shared by the forward and the inverse transform (same network).
+template <int LOG2N>
+struct FftAddr {
+    using O = PlanOps<LOG2N>;
+    using P = typename O::P;
+    int wr0, rd0, wr1, rd1;      // byte offsets into the symbol's exchange region
+    int mid_jt;                  // twiddle index part of the middle pass
+    int pos_last;                // working-array position bits held by this thread in the last pass (= output bin bits)
+    int in_thread;               // input index bits held by this thread in the first pass
+
+    __device__ __forceinline__ void init(int t, int slot, int sym_bytes)
+    {
+        constexpr int LAST = O::kLast;
+        pos_last = O::template thr_pos<LAST>(t);
+        in_thread = 0;   // bitrev_n(thr_pos<0>(t))
+        static_for<O::kNT>([&](auto U) { constexpr int u = U; constexpr int ib = LOG2N - 1 - P::kThrBit[0][u]; in_thread |= ((t >> u) & 1) << ib; });
+        wr0 = slot * sym_bytes + O::template thr_addr<0, 0>(t);
+        rd0 = slot * sym_bytes + O::template thr_addr<0, 1>(t);
+        wr1 = rd1 = mid_jt = 0;
+        if constexpr (O::kPasses == 3) {
+            wr1 = slot * sym_bytes + O::template thr_addr<1, 1>(t);
+            rd1 = slot * sym_bytes + O::template thr_addr<1, 2>(t);
+            mid_jt = O::template thr_pos<1>(t) & ((1 << P::kC0[1]) - 1);
+        }
+    }
+    // input index (first pass) / output index (last pass) of register m
+    static constexpr int in_reg(int m) { return O::bitrev(O::reg_pos(0, m), LOG2N); }
+    static constexpr int out_reg(int m) { return O::reg_pos(O::kLast, m); }
+};
+
+// Twiddles of one direction: first pass lane-uniform (scalar registers), middle pass in an LDS
+// table, last pass in per-thread registers.
+template <int LOG2N>
+struct FftTwiddles {
+    using O = PlanOps<LOG2N>;
+    using P = typename O::P;
+    float2 first[(1 << P::kR[0]) - 1];
+    float2 last[O::kLastTwCount];
+    const float2* mid;           // LDS
+
+    // fills the LDS table (callers __syncthreads() before the first run) and the registers
+    __device__ __forceinline__ void init(const float2* __restrict__ tw, float2* lds_mid, int tid, const FftAddr<LOG2N>& a)
+    {
+        constexpr int LAST = O::kLast;
+        static_for<(1 << P::kR[0]) - 1>([&](auto I) { constexpr int i = I; first[i] = tw[i]; });
+        if constexpr (O::kMidCount > 0) {
+            for (int i = tid; i < O::kMidCount; i += O::kWG) lds_mid[i] = tw[O::kMidFirst + i];
+        }
+        mid = lds_mid;
+        const int jt = a.pos_last & ((1 << P::kC0[LAST]) - 1);
+        static_for<P::kR[LAST]>([&](auto S) {
+            constexpr int s = S;
+            constexpr int c = P::kC0[LAST] + s;
+            constexpr int mask = O::last_low_mask(c);
+            static_for<(1 << O::popcount(mask))>([&](auto K) {
+                constexpr int key = K;
+                constexpr int jm = O::reg_pos(LAST, O::pdep(key, mask)) & ((1 << c) - 1);
+                last[O::last_tw_offset(s) + key] = tw[(1 << c) - 1 + jm + jt];
+            });
+        });
+    }
+};
+
+// All stages of the network on one symbol: x enters in the first-pass register pattern and
+// leaves in the last-pass pattern (natural order bins).  Contains the workgroup barriers of the
+// exchanges; the caller barriers before the exchange region is reused.
+template <int LOG2N>
+__device__ __forceinline__ void fft_run(float2 (&x)[PlanOps<LOG2N>::kE], unsigned char* lds_data, const FftAddr<LOG2N>& a, const FftTwiddles<LOG2N>& w)
+{
+    using O = PlanOps<LOG2N>;
+    using P = typename O::P;
+    constexpr int E = O::kE, LAST = O::kLast;
+    static_for<P::kR[0]>([&](auto S) {
+        constexpr int c = P::kC0[0] + S;
+        constexpr int bi = O::bfly_bit(0, c);
+        static_for<E / 2>([&](auto H) {
+            constexpr int m0 = O::insert_zero(H, bi), m1 = m0 | (1 << bi);
+            constexpr int j = O::reg_pos(0, m0) & ((1 << c) - 1);
+            bfly(x[m0], x[m1], w.first[(1 << c) - 1 + j]);
+        });
+    });
+    static_for<E>([&](auto M) { constexpr int m = M; *reinterpret_cast<float2*>(lds_data + a.wr0 + O::reg_addr(0, 0, m)) = x[m]; });
+    __syncthreads();
+    static_for<E>([&](auto M) { constexpr int m = M; x[m] = *reinterpret_cast<const float2*>(lds_data + a.rd0 + O::reg_addr(0, 1, m)); });
+    if constexpr (O::kPasses == 3) {
+        static_for<P::kR[1]>([&](auto S) {
+            constexpr int c = P::kC0[1] + S;
+            constexpr int bi = O::bfly_bit(1, c);
+            static_for<E / 2>([&](auto H) {
+                constexpr int m0 = O::insert_zero(H, bi), m1 = m0 | (1 << bi);
+                constexpr int jm = O::reg_pos(1, m0) & ((1 << c) - 1);
+                bfly(x[m0], x[m1], w.mid[(1 << c) - 1 - O::kMidFirst + jm + a.mid_jt]);
+            });
+        });
+        __syncthreads();   // all reads of exchange 0 done before the region is rewritten
+        static_for<E>([&](auto M) { constexpr int m = M; *reinterpret_cast<float2*>(lds_data + a.wr1 + O::reg_addr(1, 1, m)) = x[m]; });
+        __syncthreads();
+        static_for<E>([&](auto M) { constexpr int m = M; x[m] = *reinterpret_cast<const float2*>(lds_data + a.rd1 + O::reg_addr(1, 2, m)); });
+    }
+    static_for<P::kR[LAST]>([&](auto S) {
+        constexpr int s = S;
+        constexpr int c = P::kC0[LAST] + s;
+        constexpr int bi = O::bfly_bit(LAST, c);
+        constexpr int mask = O::last_low_mask(c);
+        static_for<E / 2>([&](auto H) {
+            constexpr int m0 = O::insert_zero(H, bi), m1 = m0 | (1 << bi);
+            bfly(x[m0], x[m1], w.last[O::last_tw_offset(s) + O::pext(m0, mask)]);
+        });
+    });
+}
+
 typedef float sdr_v4f __attribute__((ext_vector_type(4)));
 typedef float sdr_v2f __attribute__((ext_vector_type(2)));
 
@@ -253,46 +366,19 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) SDR_WAVES_ATTR rx_fused_k
     constexpr int STG_OFF = (DATA_BYTES + TW_BYTES + IDX_BYTES + 15) & ~15;
     __shared__ __attribute__((aligned(16))) unsigned char lds[STG_OFF + STG_BYTES + 16];
     unsigned char* lds_data = lds;
-    const float2* lds_tw = reinterpret_cast<const float2*>(lds + DATA_BYTES);
     unsigned char* lds_idx = lds + DATA_BYTES + TW_BYTES;
 
     const int tid = threadIdx.x;
     const int slot = tid / TPS;
     const int t = tid % TPS;
 
-    // ---- per-workgroup set-up: twiddles ----
-    float2 tw_first[(1 << P::kR[0]) - 1];
-    static_for<(1 << P::kR[0]) - 1>([&](auto I) { constexpr int i = I; tw_first[i] = p.tw[i]; });
-    if constexpr (O::kMidCount > 0) {
-        float2* dst = reinterpret_cast<float2*>(lds + DATA_BYTES);
-        for (int i = tid; i < O::kMidCount; i += O::kWG) dst[i] = p.tw[O::kMidFirst + i];
-    }
-    const int pos_last = O::template thr_pos<LAST>(t);
-    float2 tw_last[O::kLastTwCount];
-    {
-        const int jt = pos_last & ((1 << P::kC0[LAST]) - 1);
-        static_for<P::kR[LAST]>([&](auto S) {
-            constexpr int s = S;
-            constexpr int c = P::kC0[LAST] + s;
-            constexpr int mask = O::last_low_mask(c);
-            static_for<(1 << O::popcount(mask))>([&](auto K) {
-                constexpr int key = K;
-                constexpr int jm = O::reg_pos(LAST, O::pdep(key, mask)) & ((1 << c) - 1);
-                tw_last[O::last_tw_offset(s) + key] = p.tw[(1 << c) - 1 + jm + jt];
-            });
-        });
-    }
-    // loop-invariant address parts
-    int in_thread = 0;   // input index contributed by the thread bits: bitrev_n(thr_pos<0>(t))
-    static_for<O::kNT>([&](auto U) { constexpr int u = U; constexpr int ib = LOG2N - 1 - P::kThrBit[0][u]; in_thread |= ((t >> u) & 1) << ib; });
-    const int wr0 = slot * SYM_BYTES + O::template thr_addr<0, 0>(t);
-    const int rd0 = slot * SYM_BYTES + O::template thr_addr<0, 1>(t);
-    int wr1 = 0, rd1 = 0, mid_jt = 0;
-    if constexpr (O::kPasses == 3) {
-        wr1 = slot * SYM_BYTES + O::template thr_addr<1, 1>(t);
-        rd1 = slot * SYM_BYTES + O::template thr_addr<1, 2>(t);
-        mid_jt = O::template thr_pos<1>(t) & ((1 << P::kC0[1]) - 1);
-    }
+    // ---- per-workgroup set-up: addresses and twiddles ----
+    FftAddr<LOG2N> addr;
+    addr.init(t, slot, SYM_BYTES);
+    FftTwiddles<LOG2N> tw;
+    tw.init(p.tw, reinterpret_cast<float2*>(lds + DATA_BYTES), tid, addr);
+    const int pos_last = addr.pos_last;
+    const int in_thread = addr.in_thread;
 
     unsigned long long c_bit = 0, c_sym = 0, c_abs = 0, c_sign = 0, c_n = 0;
 
@@ -340,49 +426,7 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) SDR_WAVES_ATTR rx_fused_k
 #else
         load_symbol(grp, x);
 #endif
-        static_for<P::kR[0]>([&](auto S) {
-            constexpr int c = P::kC0[0] + S;
-            constexpr int bi = O::bfly_bit(0, c);
-            static_for<E / 2>([&](auto H) {
-                constexpr int m0 = O::insert_zero(H, bi), m1 = m0 | (1 << bi);
-                constexpr int j = O::reg_pos(0, m0) & ((1 << c) - 1);
-                bfly(x[m0], x[m1], tw_first[(1 << c) - 1 + j]);
-            });
-        });
-        // ---- exchange 0 ----
-        static_for<E>([&](auto M) { constexpr int m = M; *reinterpret_cast<float2*>(lds_data + wr0 + O::reg_addr(0, 0, m)) = x[m]; });
-        __syncthreads();
-        static_for<E>([&](auto M) { constexpr int m = M; x[m] = *reinterpret_cast<const float2*>(lds_data + rd0 + O::reg_addr(0, 1, m)); });
-
-        if constexpr (O::kPasses == 3) {
-            // ---- pass 1 (middle): twiddles from the LDS table ----
-            static_for<P::kR[1]>([&](auto S) {
-                constexpr int c = P::kC0[1] + S;
-                constexpr int bi = O::bfly_bit(1, c);
-                static_for<E / 2>([&](auto H) {
-                    constexpr int m0 = O::insert_zero(H, bi), m1 = m0 | (1 << bi);
-                    constexpr int jm = O::reg_pos(1, m0) & ((1 << c) - 1);
-                    const float2 w = lds_tw[(1 << c) - 1 - O::kMidFirst + jm + mid_jt];
-                    bfly(x[m0], x[m1], w);
-                });
-            });
-            __syncthreads();   // all reads of exchange 0 done before the region is rewritten
-            static_for<E>([&](auto M) { constexpr int m = M; *reinterpret_cast<float2*>(lds_data + wr1 + O::reg_addr(1, 1, m)) = x[m]; });
-            __syncthreads();
-            static_for<E>([&](auto M) { constexpr int m = M; x[m] = *reinterpret_cast<const float2*>(lds_data + rd1 + O::reg_addr(1, 2, m)); });
-        }
-
-        // ---- last pass: twiddles from registers ----
-        static_for<P::kR[LAST]>([&](auto S) {
-            constexpr int s = S;
-            constexpr int c = P::kC0[LAST] + s;
-            constexpr int bi = O::bfly_bit(LAST, c);
-            constexpr int mask = O::last_low_mask(c);
-            static_for<E / 2>([&](auto H) {
-                constexpr int m0 = O::insert_zero(H, bi), m1 = m0 | (1 << bi);
-                bfly(x[m0], x[m1], tw_last[O::last_tw_offset(s) + O::pext(m0, mask)]);
-            });
-        });
+        fft_run<LOG2N>(x, lds_data, addr, tw);
 
         // ---- epilogue: bins are in natural order, k = reg_pos(LAST, m) | pos_last ----
         constexpr int GO = O::kGroupOut;   // adjacent bins held in registers m = GO*h + (0..GO-1)

@@ -118,7 +118,8 @@ def test_fft2_golden(ctx):
 
 
 # ---- ofdm::rx / tx batched -------------------------------------------------------------------
-@pytest.mark.parametrize("n,cp", [(8, 8), (64, 16), (256, 64), (1024, 256), (2048, 512), (4096, 1024), (128, 0), (512, 37)])
+@pytest.mark.parametrize("n,cp", [(8, 8), (64, 16), (256, 64), (1024, 256), (2048, 512), (4096, 1024), (128, 0), (512, 37), (128, 32), (512, 128),
+                                  (16, 4), (8192, 2048), (1024, 1024)])
 def test_ofdm_rx_tx_bit_exact(ctx, oracle, n, cp):
     rng = np.random.default_rng(n + cp)
     s = 7
@@ -248,7 +249,8 @@ def test_demod_outputs_are_optional(ctx, oracle):
 
 
 # ---- generator / AWGN / Monte-Carlo link ---------------------------------------------------------
-@pytest.mark.parametrize("n,cp,bps", [(64, 16, 2), (1024, 256, 4), (2048, 512, 6), (4096, 1024, 8), (256, 64, 1), (512, 128, 10)])
+@pytest.mark.parametrize("n,cp,bps", [(64, 16, 2), (1024, 256, 4), (2048, 512, 6), (4096, 1024, 8), (256, 64, 1), (512, 128, 10), (128, 32, 8), (512, 128, 6),
+                                      (32, 8, 4), (8192, 2048, 2), (1024, 1024, 4), (1024, 0, 2)])
 def test_link_generate_bit_exact(ctx, oracle, n, cp, bps):
     n_sym = 6
     rx, bits = ctx.link_generate(n, cp, bps, seed=7, first_symbol=3, n_sym=n_sym, sigma=0.02)
@@ -267,7 +269,8 @@ def test_link_generate_with_channel(ctx, oracle):
 
 
 @pytest.mark.parametrize("n,cp,bps,ebn0", [(64, 16, 2, 4.0), (1024, 256, 4, 8.0), (1024, 256, 6, 12.0), (1024, 256, 8, 16.0),
-                                           (2048, 512, 6, 12.0), (4096, 1024, 8, 18.0), (256, 64, 2, 3.0)])
+                                           (2048, 512, 6, 12.0), (4096, 1024, 8, 18.0), (256, 64, 2, 3.0), (128, 32, 4, 7.0), (512, 128, 1, 3.0),
+                                           (32, 8, 2, 4.0), (8192, 2048, 4, 8.0), (1024, 256, 10, 20.0)])
 def test_link_ber_counters_bit_exact(ctx, oracle, n, cp, bps, ebn0):
     from sdr_amd.link import noise_sigma, llr_weight
     n_sym = 28 if n <= 1024 else 14
