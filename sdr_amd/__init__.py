@@ -14,6 +14,6 @@ def __getattr__(name):
         from .ops import Context
         return Context
     if name == "link":
-        from . import link
-        return link
+        import importlib
+        return importlib.import_module(".link", __name__)
     raise AttributeError(name)

@@ -309,3 +309,29 @@ def test_large_batch_properties(ctx):
     assert ((fab - fa - fb).abs().amax(dim=1) / fab.abs().amax(dim=1)).max().item() < 1e-5
     ref = torch.fft.fft(a[:64].to(torch.complex128), dim=1)
     assert ((fa[:64] - ref).abs().amax(dim=1) / ref.abs().amax(dim=1)).max().item() < 5e-6
+
+
+@pytest.mark.parametrize("n,cp,bps,ebn0", [(1024, 256, 4, 9.0), (1024, 256, 6, 13.0), (2048, 512, 6, 13.0), (4096, 1024, 8, 19.0), (64, 16, 2, 5.0)])
+def test_full_size_two_paths_agree(ctx, n, cp, bps, ebn0):
+    """Size-independent property at a batch far beyond what the oracle can check: the frame
+    generator + fused receive kernel (through HBM) and the fully fused Monte-Carlo kernel (nothing
+    in HBM) are different code paths over the same random streams, so all their counters must be
+    identical; and hard bits with LLR signs must reproduce the error count."""
+    from sdr_amd.link import noise_sigma, llr_weight
+    n_sym = (1 << 26) // n                      # 64 Mi subcarriers per case
+    sigma, w = noise_sigma(n, bps, ebn0), llr_weight(bps, ebn0)
+    rx, bits = ctx.link_generate(n, cp, bps, seed=77, first_symbol=1000, n_sym=n_sym, sigma=sigma)
+    c1 = torch.zeros(8, dtype=torch.int64, device="cuda")
+    out = ctx.demod(rx, n, cp, bps, llr_weight=w, want_hard=True, ref_hard=bits, counters=c1)
+    c2 = ctx.link_ber(n, cp, bps, seed=77, first_symbol=1000, n_sym=n_sym, sigma=sigma, llr_weight=w)
+    assert torch.equal(c1, c2), (c1.tolist(), c2.tolist())
+    assert c1[1].item() == n_sym * n * bps and c1[0].item() > 0
+    diff = torch.bitwise_xor(out.hard, bits)
+    lut = torch.tensor([bin(i).count("1") for i in range(256)], dtype=torch.int64, device="cuda")
+    assert int(lut[diff.long()].sum().item()) == c1[0].item()
+    # LLR-only variant of the kernel writes the same LLRs as the all-outputs variant
+    llr_only = ctx.demod(rx, n, cp, bps, llr_weight=w).llr
+    assert torch.equal(llr_only, out.llr)
+    sign_bits = (llr_only < 0).reshape(-1, 8).to(torch.uint8)
+    packed = (sign_bits * torch.tensor([128, 64, 32, 16, 8, 4, 2, 1], dtype=torch.uint8, device="cuda")).sum(dim=1).to(torch.uint8)
+    assert int(lut[torch.bitwise_xor(packed, bits).long()].sum().item()) == c1[6].item()
