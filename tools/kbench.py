@@ -20,11 +20,14 @@ def main():
     ap.add_argument("--symbols", type=int, default=0, help="symbols per case (default: ~8 GiB of input+output)")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--repeat", type=int, default=1, help="time every case this many times (interleaved) and report the median")
     args = ap.parse_args()
     import torch
     from sdr_amd.ops import Context
     ctx = Context(0)
-    for case in args.cases:
+    import statistics
+    results = {}
+    for case in args.cases * args.repeat:
         parts = case.split(":")
         n, bps = int(parts[0]), int(parts[1])
         with_eq = len(parts) > 2 and parts[2] == "eq"
@@ -56,11 +59,16 @@ def main():
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / args.steps
         gbs = bytes_sym * n_sym / ms / 1e6
-        print(f"case {case:>12s} n_sym {n_sym:8d}  {ms:8.3f} ms/launch  {n_sym / ms / 1e3:9.2f} Msym/s  {gbs:8.1f} GB/s  {gbs / 80:5.1f} % of 8 TB/s", flush=True)
+        results.setdefault(case, []).append(gbs)
+        if args.repeat == 1:
+            print(f"case {case:>12s} n_sym {n_sym:8d}  {ms:8.3f} ms/launch  {n_sym / ms / 1e3:9.2f} Msym/s  {gbs:8.1f} GB/s  {gbs / 80:5.1f} % of 8 TB/s", flush=True)
         del rx, eq, wgt
         if bps:
             del out
         torch.cuda.empty_cache()
+    if args.repeat > 1:
+        for case, v in results.items():
+            print(f"case {case:>12s} median {statistics.median(v):8.1f} GB/s ({statistics.median(v) / 80:5.1f} %)  min {min(v):8.1f}  max {max(v):8.1f}  n={len(v)}", flush=True)
     ctx.close()
 
 
