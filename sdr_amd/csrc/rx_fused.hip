@@ -9,28 +9,28 @@
 
 namespace sdr {
 
-int rx_fused_dispatch_6(sdr_ctx*, const RxParams&, int, bool);
-int rx_fused_dispatch_7(sdr_ctx*, const RxParams&, int, bool);
-int rx_fused_dispatch_8(sdr_ctx*, const RxParams&, int, bool);
-int rx_fused_dispatch_9(sdr_ctx*, const RxParams&, int, bool);
-int rx_fused_dispatch_10(sdr_ctx*, const RxParams&, int, bool);
-int rx_fused_dispatch_11(sdr_ctx*, const RxParams&, int, bool);
-int rx_fused_dispatch_12(sdr_ctx*, const RxParams&, int, bool);
+int rx_fused_dispatch_6(sdr_ctx*, const RxParams&, int, int);
+int rx_fused_dispatch_7(sdr_ctx*, const RxParams&, int, int);
+int rx_fused_dispatch_8(sdr_ctx*, const RxParams&, int, int);
+int rx_fused_dispatch_9(sdr_ctx*, const RxParams&, int, int);
+int rx_fused_dispatch_10(sdr_ctx*, const RxParams&, int, int);
+int rx_fused_dispatch_11(sdr_ctx*, const RxParams&, int, int);
+int rx_fused_dispatch_12(sdr_ctx*, const RxParams&, int, int);
 
 namespace {
 
 bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
-int dispatch(sdr_ctx* ctx, unsigned log2n, const RxParams& p, int mod, bool full)
+int dispatch(sdr_ctx* ctx, unsigned log2n, const RxParams& p, int mod, int variant)
 {
     switch (log2n) {
-        case 6: return rx_fused_dispatch_6(ctx, p, mod, full);
-        case 7: return rx_fused_dispatch_7(ctx, p, mod, full);
-        case 8: return rx_fused_dispatch_8(ctx, p, mod, full);
-        case 9: return rx_fused_dispatch_9(ctx, p, mod, full);
-        case 10: return rx_fused_dispatch_10(ctx, p, mod, full);
-        case 11: return rx_fused_dispatch_11(ctx, p, mod, full);
-        case 12: return rx_fused_dispatch_12(ctx, p, mod, full);
+        case 6: return rx_fused_dispatch_6(ctx, p, mod, variant);
+        case 7: return rx_fused_dispatch_7(ctx, p, mod, variant);
+        case 8: return rx_fused_dispatch_8(ctx, p, mod, variant);
+        case 9: return rx_fused_dispatch_9(ctx, p, mod, variant);
+        case 10: return rx_fused_dispatch_10(ctx, p, mod, variant);
+        case 11: return rx_fused_dispatch_11(ctx, p, mod, variant);
+        case 12: return rx_fused_dispatch_12(ctx, p, mod, variant);
         default: return fail(SDR_ERR_UNSUPPORTED, "n_fft = 2^%u has no fused kernel", log2n);
     }
 }
@@ -74,7 +74,8 @@ int rx_fused_launch(sdr_ctx* ctx, const sdr_demod_args& a)
     p.w0 = a.llr_weight0;
     p.inorm = std::sqrt(static_cast<float>(grid_energy(static_cast<int>(a.mod))));
     const bool full = a.d_hard || a.d_fft || a.d_counters || !a.d_llr || a.mod == 1;
-    return dispatch(ctx, ilog2(a.n_fft), p, static_cast<int>(a.mod), full);
+    const int variant = (full ? 2 : 0) | ((a.d_eq || a.d_llr_weight) ? 1 : 0);
+    return dispatch(ctx, ilog2(a.n_fft), p, static_cast<int>(a.mod), variant);
 }
 
 int rx_fft_only_launch(sdr_ctx* ctx, const void* d_in, uint32_t n_fft, uint32_t cp, uint64_t n_sym, void* d_out)
@@ -87,7 +88,7 @@ int rx_fft_only_launch(sdr_ctx* ctx, const void* d_in, uint32_t n_fft, uint32_t 
     p.fft = static_cast<float2*>(d_out);
     p.n_sym = n_sym;
     p.cp = cp;
-    return dispatch(ctx, ilog2(n_fft), p, 0, true);
+    return dispatch(ctx, ilog2(n_fft), p, 0, 2);
 }
 
 } // namespace sdr

@@ -343,11 +343,18 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 #ifdef SDR_WPE
 #define SDR_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(SDR_WPE, SDR_WPE)))
 #else
-#define SDR_WAVES_ATTR
+// The tap-prefetching variant must not drift above the register budget of the plain one: left
+// alone the scheduler spends 256+ registers on it and the CU drops to one wave per SIMD.
+#ifndef SDR_EQ_WPE
+#define SDR_EQ_WPE 2
+#endif
+#define SDR_WAVES_ATTR __attribute__((amdgpu_waves_per_eu((EQ || FULL) ? SDR_EQ_WPE : 1)))
 #endif
 
 // MI + MQ == 0: FFT only (bins to p.fft).  FULL: every output optional at run time.
-template <int LOG2N, int MI, int MQ, bool FULL>
+// EQ: per-subcarrier taps / LLR weights may be given; they are fetched before the transform so
+// that their latency hides under it (costs registers, hence a separate instantiation).
+template <int LOG2N, int MI, int MQ, bool FULL, bool EQ>
 __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) SDR_WAVES_ATTR rx_fused_kernel(const RxParams p)
 {
     using O = PlanOps<LOG2N>;
@@ -440,6 +447,38 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) SDR_WAVES_ATTR rx_fused_k
 #else
         load_symbol(grp, x);
 #endif
+        // Taps and weights of this thread's output bins are requested here, right behind the
+        // samples, and arrive during the transform.  The requests are unconditional: a load under
+        // a run-time branch makes the compiler's wait-count bookkeeping fall back to "wait for
+        // everything" at the next join, which would put the whole latency in front of the
+        // transform.  A missing array is replaced by an always-valid dummy source (this symbol's
+        // own samples) whose values are never used.
+        [[maybe_unused]] float2 eqv[EQ ? E : 1];
+        [[maybe_unused]] float wv[EQ ? E : 1];
+        constexpr bool PREFETCH_TAPS = EQ && DEMAP && !FULL;       // FULL has no registers to spare: it reads taps in place
+        [[maybe_unused]] size_t tap_set = 0;
+        if constexpr (EQ && DEMAP) tap_set = p.sym_per_set ? static_cast<size_t>(sym / p.sym_per_set) : 0;
+        if constexpr (PREFETCH_TAPS) {
+            constexpr int GO_ = O::kGroupOut;
+            const float2* dummy = p.rx + static_cast<size_t>(sym) * in_stride;      // >= N readable float2
+            const float2* eq_src = p.eq ? p.eq + tap_set * N : dummy;
+            const float* wgt_src = p.wgt ? p.wgt + tap_set * N : reinterpret_cast<const float*>(dummy);
+            static_for<E / GO_>([&](auto Hh) {
+                constexpr int h = Hh;
+                const int k = O::reg_pos(LAST, h * GO_) | pos_last;
+                if constexpr (GO_ == 2) {
+                    const float4 v = *reinterpret_cast<const float4*>(eq_src + k);
+                    eqv[h * 2] = make_float2(v.x, v.y);
+                    eqv[h * 2 + 1] = make_float2(v.z, v.w);
+                    const float2 u = *reinterpret_cast<const float2*>(wgt_src + k);
+                    wv[h * 2] = u.x;
+                    wv[h * 2 + 1] = u.y;
+                } else {
+                    static_for<GO_>([&](auto G) { constexpr int g = G; eqv[h * GO_ + g] = eq_src[k + g]; wv[h * GO_ + g] = wgt_src[k + g]; });
+                }
+            });
+        }
+
         fft_run<LOG2N>(x, lds_data, addr, tw);
 
         // ---- epilogue: bins are in natural order, k = reg_pos(LAST, m) | pos_last ----
@@ -459,9 +498,6 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) SDR_WAVES_ATTR rx_fused_k
             }
         }
         if constexpr (DEMAP) {
-            const size_t set = p.sym_per_set ? static_cast<size_t>(sym / p.sym_per_set) : 0;
-            const float2* eq = p.eq ? p.eq + set * N : nullptr;
-            const float* wgt = p.wgt ? p.wgt + set * N : nullptr;
             static_for<E / GO>([&](auto Hh) {
                 constexpr int h = Hh;
                 const int k = O::reg_pos(LAST, h * GO) | pos_last;
@@ -470,13 +506,21 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) SDR_WAVES_ATTR rx_fused_k
                 static_for<GO>([&](auto G) {
                     constexpr int g = G;
                     float2 y = x[h * GO + g];
-                    if (eq) {
-                        const float2 gk = eq[k + g];
-                        const float er = y.x * gk.x - y.y * gk.y;
-                        const float ei = y.x * gk.y + y.y * gk.x;
-                        y.x = er; y.y = ei;
+                    float w = p.w0;
+                    if constexpr (EQ) {
+                        if (p.eq) {
+                            float2 gk;
+                            if constexpr (PREFETCH_TAPS) gk = eqv[h * GO + g];
+                            else gk = p.eq[tap_set * N + k + g];
+                            const float er = y.x * gk.x - y.y * gk.y;
+                            const float ei = y.x * gk.y + y.y * gk.x;
+                            y.x = er; y.y = ei;
+                        }
+                        if (p.wgt) {
+                            if constexpr (PREFETCH_TAPS) w = wv[h * GO + g];
+                            else w = p.wgt[tap_set * N + k + g];
+                        }
                     }
-                    const float w = wgt ? wgt[k + g] : p.w0;
                     idx[g] = demap_point<float, MI, MQ, true, FULL>(y.x, y.y, p.inorm, w, l + g * BPS);
                 });
                 if constexpr (STAGE) {
@@ -571,18 +615,18 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) SDR_WAVES_ATTR rx_fused_k
     }
 }
 
-template <int LOG2N, int MI, int MQ, bool FULL>
+template <int LOG2N, int MI, int MQ, bool FULL, bool EQ>
 int launch_rx_fused(sdr_ctx* ctx, const RxParams& p)
 {
     using O = PlanOps<LOG2N>;
-    auto kern = rx_fused_kernel<LOG2N, MI, MQ, FULL>;
+    auto kern = rx_fused_kernel<LOG2N, MI, MQ, FULL, EQ>;
     static int blocks_per_cu = 0;
     if (blocks_per_cu == 0) {
         int nb = 0;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, O::kWG, 0);
         if (e != hipSuccess) return fail_hip(e, "hipOccupancyMaxActiveBlocksPerMultiprocessor");
         blocks_per_cu = nb > 0 ? nb : 1;
-        if (getenv("SDR_DEBUG")) fprintf(stderr, "[sdr] rx_fused<%d,%d,%d,%d>: %d threads/WG, %d WG/CU, %d CUs\n", LOG2N, MI, MQ, int(FULL), O::kWG, blocks_per_cu, ctx->num_cu);
+        if (getenv("SDR_DEBUG")) fprintf(stderr, "[sdr] rx_fused<%d,%d,%d,%d,%d>: %d threads/WG, %d WG/CU, %d CUs\n", LOG2N, MI, MQ, int(FULL), int(EQ), O::kWG, blocks_per_cu, ctx->num_cu);
     }
     const unsigned long long n_groups = (p.n_sym + O::kSPW - 1) / O::kSPW;
     // Each workgroup takes a run of consecutive symbol groups.  Short runs (many workgroups, the

@@ -13,19 +13,29 @@ namespace sdr {
 #define SDR_CAT_(a, b) a##b
 #define SDR_CAT(a, b) SDR_CAT_(a, b)
 
-// mod = 0: FFT only.  full: all outputs optional (hard bits, bins, counters); otherwise LLR only.
-int SDR_CAT(rx_fused_dispatch_, SDR_LOG2N)(sdr_ctx* ctx, const RxParams& p, int mod, bool full)
+// mod = 0: FFT only.  variant bit 0: per-subcarrier taps / weights are given (prefetching
+// instantiation); bit 1: every output optional (hard bits, bins, counters).
+int SDR_CAT(rx_fused_dispatch_, SDR_LOG2N)(sdr_ctx* ctx, const RxParams& p, int mod, int variant)
 {
     constexpr int L = SDR_LOG2N;
+#define SDR_RX_CASE(MI, MQ)                                                    \
+    switch (variant) {                                                         \
+        case 0: return launch_rx_fused<L, MI, MQ, false, false>(ctx, p);       \
+        case 1: return launch_rx_fused<L, MI, MQ, false, true>(ctx, p);        \
+        case 2: return launch_rx_fused<L, MI, MQ, true, false>(ctx, p);        \
+        default: return launch_rx_fused<L, MI, MQ, true, true>(ctx, p);        \
+    }
     switch (mod) {
-        case 0: return launch_rx_fused<L, 0, 0, true>(ctx, p);
-        case 1: return launch_rx_fused<L, 1, 0, true>(ctx, p);      // BPSK: full variant only
-        case 2: return full ? launch_rx_fused<L, 1, 1, true>(ctx, p) : launch_rx_fused<L, 1, 1, false>(ctx, p);
-        case 4: return full ? launch_rx_fused<L, 2, 2, true>(ctx, p) : launch_rx_fused<L, 2, 2, false>(ctx, p);
-        case 6: return full ? launch_rx_fused<L, 3, 3, true>(ctx, p) : launch_rx_fused<L, 3, 3, false>(ctx, p);
-        case 8: return full ? launch_rx_fused<L, 4, 4, true>(ctx, p) : launch_rx_fused<L, 4, 4, false>(ctx, p);
+        case 0: return launch_rx_fused<L, 0, 0, true, false>(ctx, p);
+        case 1:                                                       // BPSK: full variants only
+            return (variant & 1) ? launch_rx_fused<L, 1, 0, true, true>(ctx, p) : launch_rx_fused<L, 1, 0, true, false>(ctx, p);
+        case 2: SDR_RX_CASE(1, 1)
+        case 4: SDR_RX_CASE(2, 2)
+        case 6: SDR_RX_CASE(3, 3)
+        case 8: SDR_RX_CASE(4, 4)
         default: return fail(SDR_ERR_UNSUPPORTED, "modulation %d has no fused kernel", mod);
     }
+#undef SDR_RX_CASE
 }
 
 } // namespace sdr

@@ -3,7 +3,8 @@
 
   python tools/kbench.py --cases 1024:4 1024:6 1024:0 4096:8 --symbols 262144 --steps 10
 
-case = n_fft:bps[:eq]   (bps 0 = FFT only / ofdm::rx batch; eq = per-subcarrier equaliser sets)
+case = n_fft:bps[:eq][:hard]   (bps 0 = FFT only / ofdm::rx batch; eq = per-subcarrier equaliser
+sets; hard = also packed hard bits and error counters against reference bits)
 Inputs are random complex noise (values do not change the instruction stream).
 """
 import argparse
@@ -30,7 +31,8 @@ def main():
     for case in args.cases * args.repeat:
         parts = case.split(":")
         n, bps = int(parts[0]), int(parts[1])
-        with_eq = len(parts) > 2 and parts[2] == "eq"
+        with_eq = "eq" in parts[2:]
+        with_hard = "hard" in parts[2:]
         cp = n // 4
         bytes_sym = 8 * n + (4 * n * bps if bps else 8 * n)
         n_sym = args.symbols or max(1024, min(1 << 20, (8 << 30) // (bytes_sym + 8 * cp)))
@@ -43,9 +45,16 @@ def main():
             n_sets = (n_sym + per - 1) // per
             eq = torch.randn((n_sets, n * 2), dtype=torch.float32, device="cuda", generator=g).view(torch.complex64)
             wgt = torch.rand((n_sets, n), dtype=torch.float32, device="cuda", generator=g)
+        hard = ref = cnt = None
+        if bps and with_hard:
+            hard = torch.empty(n_sym * n * bps // 8, dtype=torch.uint8, device="cuda")
+            ref = torch.randint(0, 256, (n_sym * n * bps // 8,), dtype=torch.uint8, device="cuda", generator=g)
+            cnt = torch.zeros(8, dtype=torch.int64, device="cuda")
+            bytes_sym += 2 * (n * bps // 8)
         if bps:
             out = torch.empty((n_sym, n, bps), dtype=torch.float32, device="cuda")
-            step = lambda: ctx.demod(rx, n, cp, bps, eq=eq, llr_weight=(wgt if wgt is not None else 1.5), sym_per_set=per, out_llr=out)
+            step = lambda: ctx.demod(rx, n, cp, bps, eq=eq, llr_weight=(wgt if wgt is not None else 1.5), sym_per_set=per, out_llr=out,
+                                     out_hard=hard, ref_hard=ref, counters=cnt)
         else:
             step = lambda: ctx.ofdm_rx(rx, n, cp)
         for _ in range(args.warmup):
@@ -62,7 +71,7 @@ def main():
         results.setdefault(case, []).append(gbs)
         if args.repeat == 1:
             print(f"case {case:>12s} n_sym {n_sym:8d}  {ms:8.3f} ms/launch  {n_sym / ms / 1e3:9.2f} Msym/s  {gbs:8.1f} GB/s  {gbs / 80:5.1f} % of 8 TB/s", flush=True)
-        del rx, eq, wgt
+        del rx, eq, wgt, hard, ref, cnt
         if bps:
             del out
         torch.cuda.empty_cache()
