@@ -53,7 +53,9 @@ struct sdr_ctx {
     // key: (n, inverse, is_double) -> device table of n-1 complex twiddles
     std::map<std::tuple<size_t, int, int>, void*> twiddles;
     sdr::Staging stage[8];
-    uint64_t* d_scratch_counters = nullptr;
+    // kCounterSlots x 8 partial counters; kernels add into slot (workgroup id mod kCounterSlots),
+    // fold_counters() sums them into the caller's eight and leaves them zero again.
+    unsigned long long* counter_slots = nullptr;
 };
 
 namespace sdr {
@@ -62,6 +64,10 @@ int ensure_device(sdr_ctx* ctx);
 // Device pointer to the reference-recurrence twiddle table for length n (n >= 2, power of two).
 int get_twiddles(sdr_ctx* ctx, size_t n, bool inverse, bool is_double, const void** d_table);
 int get_staging(sdr_ctx* ctx, int slot, size_t bytes, void** ptr);
+constexpr int kCounterSlots = 1024;
+int get_counter_slots(sdr_ctx* ctx, unsigned long long** slots);
+// adds the slots and the counts that need no measuring (bits, symbols, OFDM symbols) into d_counters
+int fold_counters(sdr_ctx* ctx, unsigned long long* d_counters, uint64_t n_points, uint32_t bps, uint64_t n_ofdm);
 
 // Host-side generation of the reference's per-stage twiddle sequence (lib/inc/fft.hpp:113-150).
 void make_twiddles_f32(size_t n, bool inverse, float* out);

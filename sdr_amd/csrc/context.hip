@@ -112,6 +112,68 @@ int get_staging(sdr_ctx* ctx, int slot, size_t bytes, void** ptr)
     return SDR_OK;
 }
 
+int get_counter_slots(sdr_ctx* ctx, unsigned long long** slots)
+{
+    if (!ctx->counter_slots) {
+        const size_t bytes = static_cast<size_t>(kCounterSlots) * 8 * sizeof(unsigned long long);
+        SDR_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->counter_slots), bytes));
+        SDR_HIP(hipMemsetAsync(ctx->counter_slots, 0, bytes, ctx->stream));
+    }
+    *slots = ctx->counter_slots;
+    return SDR_OK;
+}
+
+namespace {
+
+// One workgroup of kCounterSlots threads: thread t owns slot t.  Device-scope atomics on ONE
+// address from half a million workgroups serialise in the memory-side cache (measured: the
+// counting receive path ran at an eighth of its speed); spread over 1024 lines they do not.
+__global__ void __launch_bounds__(kCounterSlots) fold_counters_kernel(unsigned long long* slots, unsigned long long* out,
+                                                                      unsigned long long n_points, unsigned bps, unsigned long long n_ofdm)
+{
+    __shared__ unsigned long long part[kCounterSlots / 64][4];
+    const int t = threadIdx.x;
+    unsigned long long v[4];
+    constexpr int which[4] = {0, 2, 5, 6};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        v[j] = slots[t * 8 + which[j]];
+        slots[t * 8 + which[j]] = 0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned lo = __shfl_xor(static_cast<unsigned>(v[j]), off, 64);
+            const unsigned hi = __shfl_xor(static_cast<unsigned>(v[j] >> 32), off, 64);
+            v[j] += (static_cast<unsigned long long>(hi) << 32) | lo;
+        }
+        if ((t & 63) == 0) part[t >> 6][j] = v[j];
+    }
+    __syncthreads();
+    if (t < 4) {
+        unsigned long long s = 0;
+        for (int w = 0; w < kCounterSlots / 64; ++w) s += part[w][t];
+        atomicAdd(&out[which[t]], s);
+    } else if (t == 4) {
+        atomicAdd(&out[1], n_points * bps);
+    } else if (t == 5) {
+        atomicAdd(&out[3], n_points);
+    } else if (t == 6) {
+        atomicAdd(&out[4], n_ofdm);
+    }
+}
+
+} // namespace
+
+int fold_counters(sdr_ctx* ctx, unsigned long long* d_counters, uint64_t n_points, uint32_t bps, uint64_t n_ofdm)
+{
+    unsigned long long* slots = nullptr;
+    SDR_TRY(get_counter_slots(ctx, &slots));
+    hipLaunchKernelGGL(fold_counters_kernel, dim3(1), dim3(kCounterSlots), 0, ctx->stream, slots, d_counters,
+                       static_cast<unsigned long long>(n_points), bps, static_cast<unsigned long long>(n_ofdm));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, "fold_counters_kernel launch");
+    return SDR_OK;
+}
+
 } // namespace sdr
 
 using namespace sdr;
@@ -170,7 +232,7 @@ void sdr_destroy(sdr_ctx* ctx)
     if (ctx->stream || !ctx->own_stream) (void)hipStreamSynchronize(ctx->stream);
     for (auto& kv : ctx->twiddles) (void)hipFree(kv.second);
     for (auto& s : ctx->stage) if (s.ptr) (void)hipFree(s.ptr);
-    if (ctx->d_scratch_counters) (void)hipFree(ctx->d_scratch_counters);
+    if (ctx->counter_slots) (void)hipFree(ctx->counter_slots);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -50,7 +50,7 @@ bool rx_fused_layout_ok(const sdr_demod_args& a)
 {
     if (a.cp % 2 != 0) return false;
     if (!aligned(a.d_rx, 16) || !aligned(a.d_llr, 16) || !aligned(a.d_fft, 16) || !aligned(a.d_eq, 16) || !aligned(a.d_llr_weight, 8)) return false;
-    if (!aligned(a.d_hard, 4)) return false;
+    if (!aligned(a.d_hard, 4) || !aligned(a.d_ref_hard, 4)) return false;
     return true;
 }
 
@@ -67,7 +67,7 @@ int rx_fused_launch(sdr_ctx* ctx, const sdr_demod_args& a)
     p.hard = a.d_hard;
     p.fft = static_cast<float2*>(a.d_fft);
     p.ref = a.d_ref_hard;
-    p.counters = reinterpret_cast<unsigned long long*>(a.d_counters);
+    if (a.d_counters) SDR_TRY(get_counter_slots(ctx, &p.counters));
     p.n_sym = a.n_sym;
     p.cp = a.cp;
     p.sym_per_set = a.sym_per_set;
@@ -75,7 +75,9 @@ int rx_fused_launch(sdr_ctx* ctx, const sdr_demod_args& a)
     p.inorm = std::sqrt(static_cast<float>(grid_energy(static_cast<int>(a.mod))));
     const bool full = a.d_hard || a.d_fft || a.d_counters || !a.d_llr || a.mod == 1;
     const int variant = (full ? 2 : 0) | ((a.d_eq || a.d_llr_weight) ? 1 : 0);
-    return dispatch(ctx, ilog2(a.n_fft), p, static_cast<int>(a.mod), variant);
+    SDR_TRY(dispatch(ctx, ilog2(a.n_fft), p, static_cast<int>(a.mod), variant));
+    if (a.d_counters) SDR_TRY(fold_counters(ctx, reinterpret_cast<unsigned long long*>(a.d_counters), a.n_sym * a.n_fft, a.mod, a.n_sym));
+    return SDR_OK;
 }
 
 int rx_fft_only_launch(sdr_ctx* ctx, const void* d_in, uint32_t n_fft, uint32_t cp, uint64_t n_sym, void* d_out)

@@ -43,7 +43,7 @@ struct RxParams {
     uint8_t* hard;               // packed bits or null                 (FULL only)
     float2* fft;                 // n_sym x N or null                   (FULL / FFT-only)
     const uint8_t* ref;          // reference packed bits or null       (FULL only)
-    unsigned long long* counters;// 8 counters or null                  (FULL only)
+    unsigned long long* counters;// the context's counter slots, or null     (FULL only)
     unsigned long long n_sym;
     uint32_t cp;
     uint32_t sym_per_set;
@@ -366,15 +366,18 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) SDR_WAVES_ATTR rx_fused_k
     constexpr int DATA_BYTES = SYM_BYTES * SPW;
     constexpr int TW_BYTES = O::kMidCount * 8;
     constexpr int IDX_BYTES = (FULL && DEMAP) ? N * SPW : 0;
+    constexpr int REF_SYM_BYTES = N * (DEMAP ? BPS : 8) / 8;      // reference bits of one symbol
+    constexpr int REF_BYTES = (FULL && DEMAP) ? REF_SYM_BYTES * SPW : 0;
     constexpr int CHUNK = O::kGroupOut * BPS;                      // LLR floats per lane per output block
     constexpr bool STAGE = DEMAP && SPW == 1 && stage_wanted(CHUNK);
     constexpr int STG_STRIDE = stage_stride_bytes(CHUNK);
     constexpr int STG_WAVE_BYTES = STAGE ? 64 * STG_STRIDE : 0;
     constexpr int STG_BYTES = STG_WAVE_BYTES * (O::kWG / 64);
-    constexpr int STG_OFF = (DATA_BYTES + TW_BYTES + IDX_BYTES + 15) & ~15;
+    constexpr int STG_OFF = (DATA_BYTES + TW_BYTES + IDX_BYTES + REF_BYTES + 15) & ~15;
     __shared__ __attribute__((aligned(16))) unsigned char lds[STG_OFF + STG_BYTES + 16];
     unsigned char* lds_data = lds;
     unsigned char* lds_idx = lds + DATA_BYTES + TW_BYTES;
+    [[maybe_unused]] unsigned char* lds_ref = lds + DATA_BYTES + TW_BYTES + IDX_BYTES;
 
     const int tid = threadIdx.x;
     const int slot = tid / TPS;
@@ -388,7 +391,7 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) SDR_WAVES_ATTR rx_fused_k
     const int pos_last = addr.pos_last;
     const int in_thread = addr.in_thread;
 
-    unsigned long long c_bit = 0, c_sym = 0, c_abs = 0, c_sign = 0, c_n = 0;
+    unsigned long long c_bit = 0, c_sym = 0, c_abs = 0, c_sign = 0;
 
     const unsigned long long n_groups = (p.n_sym + SPW - 1) / SPW;
     const size_t in_stride = static_cast<size_t>(N) + p.cp;
@@ -440,6 +443,23 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) SDR_WAVES_ATTR rx_fused_k
         const bool active = sym < p.n_sym;
         if (!active) sym = p.n_sym - 1;
 
+        // Reference bits of the symbol (counting only): requested ahead of the samples, parked
+        // in LDS before the transform.  Unconditional for the same reason as the taps below; a
+        // missing array is replaced by the symbol's own samples, never looked at.
+        constexpr int REF_WORDS = REF_SYM_BYTES / 4;
+        constexpr int REF_PER_THREAD = (REF_WORDS + TPS - 1) / TPS;
+        [[maybe_unused]] uint32_t refw[REF_PER_THREAD];
+        if constexpr (FULL && DEMAP) {
+            const uint32_t* ref_src = p.ref ? reinterpret_cast<const uint32_t*>(p.ref + static_cast<size_t>(sym) * REF_SYM_BYTES)
+                                            : reinterpret_cast<const uint32_t*>(p.rx + static_cast<size_t>(sym) * in_stride);
+            static_for<REF_PER_THREAD>([&](auto R) {
+                constexpr int r = R;
+                int i = r * TPS + t;
+                if (i > REF_WORDS - 1) i = REF_WORDS - 1;
+                refw[r] = ref_src[i];
+            });
+        }
+
         // ---- pass 0 ----
 #ifdef SDR_PREFETCH
         static_for<E>([&](auto M) { constexpr int m = M; x[m] = xn[m]; });
@@ -476,6 +496,15 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) SDR_WAVES_ATTR rx_fused_k
                 } else {
                     static_for<GO_>([&](auto G) { constexpr int g = G; eqv[h * GO_ + g] = eq_src[k + g]; wv[h * GO_ + g] = wgt_src[k + g]; });
                 }
+            });
+        }
+
+        if constexpr (FULL && DEMAP) {
+            static_for<REF_PER_THREAD>([&](auto R) {
+                constexpr int r = R;
+                int i = r * TPS + t;
+                if (i > REF_WORDS - 1) i = REF_WORDS - 1;          // duplicates store the same word
+                reinterpret_cast<uint32_t*>(lds_ref)[slot * REF_WORDS + i] = refw[r];
             });
         }
 
@@ -553,22 +582,34 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) SDR_WAVES_ATTR rx_fused_k
                 if constexpr (FULL) {
                     if (p.hard) static_for<GO>([&](auto G) { constexpr int g = G; lds_idx[slot * N + k + g] = static_cast<unsigned char>(idx[g]); });
                     if (p.counters && active) {
+                        // GO adjacent points: GO * BPS <= 16 reference bits, inside two bytes
+                        static_assert(GO * BPS <= 16, "reference bits of one register group fit two bytes");
+                        const unsigned bit = static_cast<unsigned>(k) * BPS;
+                        const unsigned b0 = bit >> 3;
+                        const unsigned b1 = (b0 + 1 < REF_SYM_BYTES) ? b0 + 1 : b0;
+                        const unsigned char* rs = lds_ref + slot * REF_SYM_BYTES;
+                        const unsigned two = (static_cast<unsigned>(rs[b0]) << 8) | rs[b1];
+                        const unsigned both = (two >> (16u - (bit & 7u) - GO * BPS)) & ((1u << (GO * BPS)) - 1u);
+                        unsigned n_bit = 0, n_sym_err = 0, n_sign = 0, n_abs = 0;      // <= 16 LLRs: no overflow
+                        unsigned long long wide_abs = 0;
                         static_for<GO>([&](auto G) {
                             constexpr int g = G;
-                            const unsigned ref = ref_bits(p.ref, (bin0 + k + g) * BPS, BPS);
+                            const unsigned ref = (both >> ((GO - 1 - g) * BPS)) & ((1u << BPS) - 1u);
                             const unsigned diff = ref ^ idx[g];
-                            c_bit += __popc(diff);
-                            c_sym += (diff != 0);
-                            c_n += 1;
+                            n_bit += __popc(diff);
+                            n_sym_err += (diff != 0);
                             static_for<BPS>([&](auto B) {
                                 constexpr int b = B;
                                 const float lv = l[g * BPS + b];
                                 float a = fabsf(lv) * 1024.0f;
                                 a = (a < 1073741824.0f) ? a : 1073741824.0f;
-                                c_abs += static_cast<unsigned long long>(static_cast<long long>(a));
-                                c_sign += (((ref >> (BPS - 1 - b)) & 1u) != (lv < 0.0f ? 1u : 0u));
+                                // a in [0, 2^30]: the 32-bit truncation is the 64-bit one
+                                if constexpr ((g * BPS + b) % 2 == 1) { n_abs += static_cast<unsigned>(static_cast<int>(a)); wide_abs += n_abs; n_abs = 0; }
+                                else n_abs = static_cast<unsigned>(static_cast<int>(a));
+                                n_sign += (((ref >> (BPS - 1 - b)) & 1u) != (lv < 0.0f ? 1u : 0u));
                             });
                         });
+                        c_bit += n_bit; c_sym += n_sym_err; c_sign += n_sign; c_abs += wide_abs + n_abs;
                     }
                 }
             });
@@ -601,16 +642,16 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) SDR_WAVES_ATTR rx_fused_k
     if constexpr (FULL && DEMAP) {
         if (p.counters) {
             c_bit = wave_sum_u64(c_bit); c_sym = wave_sum_u64(c_sym); c_abs = wave_sum_u64(c_abs);
-            c_sign = wave_sum_u64(c_sign); c_n = wave_sum_u64(c_n);
+            c_sign = wave_sum_u64(c_sign);
             if ((tid & 63) == 0) {
-                atomicAdd(&p.counters[0], c_bit);
-                atomicAdd(&p.counters[1], c_n * BPS);
-                atomicAdd(&p.counters[2], c_sym);
-                atomicAdd(&p.counters[3], c_n);
-                atomicAdd(&p.counters[5], c_abs);
-                atomicAdd(&p.counters[6], c_sign);
+                // p.counters is the context's slot array here (common.hpp: kCounterSlots x 8);
+                // the host folds it into the caller's counters after the launch
+                unsigned long long* dst = p.counters + static_cast<size_t>(blockIdx.x & (kCounterSlots - 1)) * 8;
+                atomicAdd(&dst[0], c_bit);
+                atomicAdd(&dst[2], c_sym);
+                atomicAdd(&dst[5], c_abs);
+                atomicAdd(&dst[6], c_sign);
             }
-            if (blockIdx.x == 0 && tid == 0) atomicAdd(&p.counters[4], p.n_sym);
         }
     }
 }
@@ -632,7 +673,7 @@ int launch_rx_fused(sdr_ctx* ctx, const RxParams& p)
     // Each workgroup takes a run of consecutive symbol groups.  Short runs (many workgroups, the
     // hardware dispatcher balancing them) measured faster than a resident grid striding over the
     // batch; the per-workgroup twiddle set-up is amortised over the run.
-    unsigned long long per_wg = 2;
+    unsigned long long per_wg = p.counters ? 8 : 2;              // counting ends every workgroup with atomics: longer runs
     if (const char* ov = getenv("SDR_GROUPS_PER_WG")) per_wg = static_cast<unsigned long long>(atol(ov));   // tuning knob; 0 = resident grid
     if (per_wg == 0) {
         const unsigned long long resident = static_cast<unsigned long long>(ctx->num_cu) * blocks_per_cu;

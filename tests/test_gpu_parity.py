@@ -213,6 +213,17 @@ def test_demod_parity(ctx, oracle, n, cp, bps):
     c = counters.cpu().numpy()
     assert c[0] == oracle.count_bit_errors(ref["hard"], bits) and c[0] > 0      # error count: bit exact
     assert c[1] == n_sym * n * bps and c[3] == n_sym * n and c[4] == n_sym
+    # the other counters, restated with numpy on the oracle's outputs
+    tx = np.unpackbits(bits).reshape(-1, bps)
+    rxb = np.unpackbits(ref["hard"]).reshape(-1, bps)
+    assert c[2] == int((tx != rxb).any(axis=1).sum())
+    l = ref["llr"].reshape(-1, bps)
+    q = np.minimum(np.abs(l) * np.float32(1024.0), np.float32(1073741824.0)).astype(np.int64)
+    assert c[5] == int(q.sum())
+    assert c[6] == int(((l < 0).astype(np.uint8) != tx).sum())
+    # a second call accumulates
+    ctx.demod(dev(rx), n, cp, bps, llr_weight=float(w), want_llr=False, ref_hard=dev(bits), counters=counters)
+    assert same(counters.cpu().numpy(), 2 * c)
 
 
 @pytest.mark.parametrize("n,cp,bps", [(64, 16, 2), (1024, 256, 4), (2048, 512, 6), (4096, 1024, 8)])
@@ -235,6 +246,27 @@ def test_demod_with_equaliser_sets(ctx, oracle, n, cp, bps):
     assert same(out.llr.cpu().numpy(), ref["llr"])
     # high SNR + zero forcing: almost every bit must come back
     assert oracle.count_bit_errors(ref["hard"], bits) < 0.02 * bits.size * 8
+
+
+@pytest.mark.parametrize("n,cp,bps", [(64, 16, 2), (256, 64, 4), (1024, 256, 4), (1024, 256, 6), (2048, 512, 6), (4096, 1024, 8), (512, 128, 2)])
+@pytest.mark.parametrize("which", ["both", "taps", "weights"])
+def test_demod_llr_only_with_taps_or_weights(ctx, oracle, n, cp, bps, which):
+    """LLR-only output takes the tap-prefetching instantiation; either array may be absent."""
+    from sdr_amd.link import noise_sigma
+    rng = np.random.default_rng(n + bps)
+    n_sym, per = 31, 7
+    n_sets = (n_sym + per - 1) // per
+    h = (rand_c(rng, (n_sets, n)) * np.float32(np.sqrt(0.5))).astype(np.complex64)
+    h[np.abs(h) < 0.1] += np.float32(0.3)
+    rx, _ = oracle.link_generate(n, cp, bps, 7, 0, n_sym, np.float32(noise_sigma(n, bps, 25.0)), chan=h, sym_per_set=per)
+    taps, wgt = oracle.zf_taps(bps, h, 20.0)
+    eq = taps if which != "weights" else None
+    wt = wgt if which != "taps" else np.float32(1.75)
+    ref = oracle.demod(rx, n, cp, bps, eq=eq, weight=wt, sym_per_set=per, want_fft=False, want_hard=False)
+    out = ctx.demod(dev(rx), n, cp, bps, eq=(dev(eq.ravel()) if eq is not None else None),
+                    llr_weight=(dev(wt.ravel()) if which != "taps" else float(wt)), sym_per_set=per)
+    assert rel_err(out.llr.cpu().numpy(), ref["llr"]) <= TOL
+    assert same(out.llr.cpu().numpy(), ref["llr"])
 
 
 def test_demod_outputs_are_optional(ctx, oracle):

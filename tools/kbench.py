@@ -3,8 +3,8 @@
 
   python tools/kbench.py --cases 1024:4 1024:6 1024:0 4096:8 --symbols 262144 --steps 10
 
-case = n_fft:bps[:eq][:hard]   (bps 0 = FFT only / ofdm::rx batch; eq = per-subcarrier equaliser
-sets; hard = also packed hard bits and error counters against reference bits)
+case = n_fft:bps[:eq][:hard][:cnt]   (bps 0 = FFT only / ofdm::rx batch; eq = per-subcarrier
+equaliser sets; hard = also packed hard bits; cnt = error counters against reference bits)
 Inputs are random complex noise (values do not change the instruction stream).
 """
 import argparse
@@ -48,9 +48,11 @@ def main():
         hard = ref = cnt = None
         if bps and with_hard:
             hard = torch.empty(n_sym * n * bps // 8, dtype=torch.uint8, device="cuda")
+            bytes_sym += n * bps // 8
+        if bps and "cnt" in parts[2:]:
             ref = torch.randint(0, 256, (n_sym * n * bps // 8,), dtype=torch.uint8, device="cuda", generator=g)
             cnt = torch.zeros(8, dtype=torch.int64, device="cuda")
-            bytes_sym += 2 * (n * bps // 8)
+            bytes_sym += n * bps // 8
         if bps:
             out = torch.empty((n_sym, n, bps), dtype=torch.float32, device="cuda")
             step = lambda: ctx.demod(rx, n, cp, bps, eq=eq, llr_weight=(wgt if wgt is not None else 1.5), sym_per_set=per, out_llr=out,
