@@ -127,7 +127,7 @@ def time_workload(ctx, torch, dist, name, steps, warmup, world, rank, n_sym_over
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=("cuda" if dist.get_backend() == "nccl" else "cpu"))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     launch_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
@@ -165,8 +165,16 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # SDR_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks (ranks share
+        # devices round-robin, barriers and the max-over-ranks go over gloo); the driver's runs use RCCL.
+        backend = os.environ.get("SDR_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            local_rank = local_rank % torch.cuda.device_count()
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
         local_rank = 0
