@@ -187,6 +187,53 @@ int sdr_link_generate_c32(sdr_ctx* ctx, const sdr_link_args* args);
 /* generate -> demodulate -> count entirely on the device; nothing but counters touches HBM. */
 int sdr_link_ber_c32(sdr_ctx* ctx, const sdr_link_args* args);
 
+/* ---- Streaming ingest ------------------------------------------------
+ * What sits in front of the path in the reference is a host-side ring that is fed one OFDM
+ * symbol at a time (utils::sliding_buffer, lib/inc/sliding_buffer.hpp:14-104, filled at
+ * app/QFDemoWindow.cpp:213-229).  The device analogue is a ring of `depth` slots, each with a
+ * pinned host input buffer, device buffers and pinned host result buffers.  The producer fills
+ * a slot's input with up to chunk_symbols received symbols and submits it; upload, the fused
+ * receive kernel (sdr_ofdm_demod_c32 on the slot) and the download of the results run on three
+ * streams, so the upload of chunk i+1 and the download of chunk i-1 overlap the kernel of chunk i.
+ *   acquire -> fill h_rx -> submit   (producer; acquire fails with SDR_ERR_INVALID when all
+ *                                     slots are in flight: collect/release first)
+ *   collect -> use results -> release (consumer; collect blocks until the oldest chunk is done)
+ * Chunks complete in submission order.  One pipe must not be used from two threads at once,
+ * except that one producer thread (acquire/submit) and one consumer thread (collect/release)
+ * may run concurrently.  Equaliser sets restart at every chunk (set 0 = first symbol of the
+ * chunk), so chunk_symbols should be a multiple of sym_per_set. */
+typedef struct sdr_pipe sdr_pipe;
+enum { SDR_PIPE_LLR_TO_HOST = 1, SDR_PIPE_HARD_TO_HOST = 2, SDR_PIPE_WANT_LLR = 4, SDR_PIPE_WANT_HARD = 8 };
+typedef struct sdr_pipe_config {
+    uint32_t struct_size;       /* = sizeof(sdr_pipe_config) */
+    uint32_t n_fft;
+    uint32_t cp;
+    uint32_t mod;               /* sdr_modulation */
+    uint64_t chunk_symbols;     /* capacity of one slot */
+    uint32_t depth;             /* slots, 2..16 */
+    uint32_t flags;             /* SDR_PIPE_*; *_TO_HOST implies the matching WANT */
+    uint32_t sym_per_set;
+    float llr_weight0;
+    const void* d_eq;           /* device, n_sets*n_fft c32 or NULL; must outlive the pipe */
+    const float* d_llr_weight;  /* device, n_sets*n_fft or NULL */
+} sdr_pipe_config;
+typedef struct sdr_pipe_result {
+    uint64_t sequence;          /* 0,1,2,... in submission order */
+    uint64_t n_sym;
+    const float* h_llr;         /* pinned host, n_sym*n_fft*mod, or NULL */
+    const uint8_t* h_hard;      /* pinned host, n_sym*n_fft*mod/8, or NULL */
+    const float* d_llr;         /* device copies of the same, valid until release, or NULL */
+    const uint8_t* d_hard;
+} sdr_pipe_result;
+int sdr_pipe_create(int device, const sdr_pipe_config* config, sdr_pipe** out);
+int sdr_pipe_acquire(sdr_pipe* pipe, void** h_rx);
+int sdr_pipe_submit(sdr_pipe* pipe, uint64_t n_sym);
+int sdr_pipe_collect(sdr_pipe* pipe, sdr_pipe_result* result);
+int sdr_pipe_release(sdr_pipe* pipe);
+/* Chunks submitted and not yet released. */
+int sdr_pipe_in_flight(sdr_pipe* pipe, uint32_t* count);
+void sdr_pipe_destroy(sdr_pipe* pipe);
+
 /* Host-visible pieces of the generator, for tests. */
 int sdr_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 

@@ -69,6 +69,35 @@ class LinkArgs(Structure):
     ]
 
 
+class PipeConfig(Structure):
+    _fields_ = [
+        ("struct_size", c_uint32),
+        ("n_fft", c_uint32),
+        ("cp", c_uint32),
+        ("mod", c_uint32),
+        ("chunk_symbols", c_uint64),
+        ("depth", c_uint32),
+        ("flags", c_uint32),
+        ("sym_per_set", c_uint32),
+        ("llr_weight0", c_float),
+        ("d_eq", c_void_p),
+        ("d_llr_weight", c_void_p),
+    ]
+
+
+class PipeResult(Structure):
+    _fields_ = [
+        ("sequence", c_uint64),
+        ("n_sym", c_uint64),
+        ("h_llr", c_void_p),
+        ("h_hard", c_void_p),
+        ("d_llr", c_void_p),
+        ("d_hard", c_void_p),
+    ]
+
+
+PIPE_LLR_TO_HOST, PIPE_HARD_TO_HOST, PIPE_WANT_LLR, PIPE_WANT_HARD = 1, 2, 4, 8
+
 # name -> (restype, argtypes); every symbol include/sdr_amd.h declares
 SIGNATURES = {
     "sdr_version": (c_char_p, []),
@@ -114,6 +143,13 @@ SIGNATURES = {
     "sdr_link_generate_c32": (c_int, [c_void_p, POINTER(LinkArgs)]),
     "sdr_link_ber_c32": (c_int, [c_void_p, POINTER(LinkArgs)]),
     "sdr_philox4x32_10": (c_int, [POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32)]),
+    "sdr_pipe_create": (c_int, [c_int, POINTER(PipeConfig), POINTER(c_void_p)]),
+    "sdr_pipe_acquire": (c_int, [c_void_p, POINTER(c_void_p)]),
+    "sdr_pipe_submit": (c_int, [c_void_p, c_uint64]),
+    "sdr_pipe_collect": (c_int, [c_void_p, POINTER(PipeResult)]),
+    "sdr_pipe_release": (c_int, [c_void_p]),
+    "sdr_pipe_in_flight": (c_int, [c_void_p, POINTER(c_uint32)]),
+    "sdr_pipe_destroy": (None, [c_void_p]),
 }
 
 _lib = None

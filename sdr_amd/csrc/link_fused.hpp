@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) tx_fused_kernel(const TxP
     using O = PlanOps<LOG2N>;
     using P = typename O::P;
     using A = FftAddr<LOG2N>;
-    constexpr int N = O::kN, E = O::kE, TPS = O::kTPS, SPW = O::kSPW, LAST = O::kLast;
+    constexpr int N = O::kN, E = O::kE, TPS = O::kTPS, SPW = O::kSPW;
     constexpr int BPS = MI + MQ;
     constexpr int SYM_BYTES = O::max_sym_bytes();
     constexpr int DATA_BYTES = SYM_BYTES * SPW;
@@ -232,7 +232,6 @@ template <int LOG2N, int MI, int MQ>
 __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) mc_fused_kernel(const McParams p)
 {
     using O = PlanOps<LOG2N>;
-    using P = typename O::P;
     using A = FftAddr<LOG2N>;
     constexpr int N = O::kN, E = O::kE, TPS = O::kTPS, SPW = O::kSPW;
     constexpr int BPS = MI + MQ;

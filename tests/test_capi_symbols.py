@@ -31,6 +31,8 @@ def test_struct_layouts_match_header():
     from sdr_amd import capi
     assert ctypes.sizeof(capi.DemodArgs) == 96
     assert ctypes.sizeof(capi.LinkArgs) == 88
+    assert ctypes.sizeof(capi.PipeConfig) == 56
+    assert ctypes.sizeof(capi.PipeResult) == 48
 
 
 @pytest.mark.parametrize("n", [2, 8, 64, 1024, 4096])

@@ -367,3 +367,54 @@ def test_full_size_two_paths_agree(ctx, n, cp, bps, ebn0):
     sign_bits = (llr_only < 0).reshape(-1, 8).to(torch.uint8)
     packed = (sign_bits * torch.tensor([128, 64, 32, 16, 8, 4, 2, 1], dtype=torch.uint8, device="cuda")).sum(dim=1).to(torch.uint8)
     assert int(lut[torch.bitwise_xor(packed, bits).long()].sum().item()) == c1[6].item()
+
+
+# ---- streaming ingest ----------------------------------------------------------------------------
+@pytest.mark.parametrize("n,cp,bps,chunk,depth", [(1024, 256, 4, 64, 3), (64, 16, 2, 100, 2), (2048, 512, 6, 16, 4)])
+def test_pipe_equals_one_shot_demod(ctx, oracle, n, cp, bps, chunk, depth):
+    """Chunks through the three-stream ring give exactly what one call on the whole array gives
+    (and what the oracle gives), including a ragged last chunk and more chunks than slots."""
+    from sdr_amd.link import noise_sigma
+    from sdr_amd.pipe import Pipe
+    n_sym = chunk * (2 * depth + 1) + chunk // 2
+    rx, _ = oracle.link_generate(n, cp, bps, 77, 0, n_sym, np.float32(noise_sigma(n, bps, 10.0)))
+    rx = rx.reshape(n_sym, n + cp)
+    ref = oracle.demod(rx, n, cp, bps, weight=1.25, want_fft=False)
+    with Pipe(0, n_fft=n, cp=cp, mod=bps, chunk_symbols=chunk, depth=depth, llr_to_host=True, hard_to_host=True, llr_weight=1.25) as pipe:
+        llr, hard, seqs = [], [], []
+        for c in pipe.run(rx[i:i + chunk] for i in range(0, n_sym, chunk)):
+            llr.append(c.llr.copy()); hard.append(c.hard.copy()); seqs.append(c.sequence)
+            assert c.d_llr and c.d_hard
+        assert seqs == list(range(len(seqs))) and pipe.in_flight() == 0
+    assert same(np.concatenate(llr), ref["llr"])
+    assert same(np.concatenate(hard), ref["hard"])
+
+
+def test_pipe_protocol_errors(ctx):
+    from sdr_amd import capi
+    from sdr_amd.pipe import Pipe
+    with pytest.raises(RuntimeError):
+        Pipe(0, n_fft=1000, cp=0, mod=4, chunk_symbols=8, hard_to_host=True)          # not a power of two
+    assert capi.last_error() == "The sequence size must be of powers of 2"
+    with pytest.raises(RuntimeError):
+        Pipe(0, n_fft=64, cp=16, mod=4, chunk_symbols=8)                               # no output asked for
+    with Pipe(0, n_fft=64, cp=16, mod=4, chunk_symbols=8, depth=2, hard_to_host=True) as pipe:
+        with pytest.raises(RuntimeError):
+            pipe.submit(4)                                                              # submit without acquire
+        with pytest.raises(RuntimeError):
+            pipe.collect()                                                              # nothing submitted
+        for _ in range(2):
+            pipe.acquire()[:] = 0
+            pipe.submit(8)
+        with pytest.raises(RuntimeError):
+            pipe.acquire()                                                              # ring full
+        with pytest.raises(RuntimeError):
+            pipe.release()                                                              # nothing collected
+        c = pipe.collect()
+        assert c.n_sym == 8 and c.sequence == 0
+        pipe.release()
+        buf = pipe.acquire()
+        with pytest.raises(RuntimeError):
+            pipe.submit(9)                                                              # more than a slot holds
+        pipe.submit(1)
+        assert pipe.in_flight() == 2
