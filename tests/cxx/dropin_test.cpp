@@ -13,6 +13,7 @@
 #include "sdrlib/fft.hpp"
 #include "sdrlib/modulation.hpp"
 #include "sdrlib/ofdm.hpp"
+#include "sdrlib/pipe.hpp"
 
 static int g_failed = 0;
 #define CHECK(cond) do { if (!(cond)) { std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond); ++g_failed; } } while (0)
@@ -135,6 +136,51 @@ static void extras()
         }
 }
 
+static void streaming_pipe()         // sdrlib/pipe.hpp against demod_batch on the same samples
+{
+    constexpr uint32_t N = 64, CP = 16;
+    std::vector<uint8_t> payload(N * 4 * 10 / 8);                  // ten OFDM symbols of 16-QAM
+    for (size_t i = 0; i < payload.size(); ++i) payload[i] = uint8_t(i * 29 + 5);
+    auto freq = modulation::to_constl<modulation::e16QAM, float>(payload);
+    std::vector<std::complex<float>> air;
+    CHECK(ofdm::tx_batch(freq, N, CP, air).has_value());
+    auto whole = ofdm::demod_batch<modulation::e16QAM>(air, N, CP, 1.5f);
+    CHECK(whole.has_value());
+
+    sdrlib::pipe_options o;
+    o.n_fft = N; o.cp = CP; o.bits_per_symbol = 4; o.chunk_symbols = 4; o.depth = 2;
+    o.llr_to_host = true; o.hard_to_host = true; o.llr_weight = 1.5f;
+    auto made = sdrlib::pipe::create(o);
+    CHECK(made.has_value());
+    if (!made) return;
+    sdrlib::pipe p = std::move(*made);
+    std::vector<uint8_t> hard;
+    std::vector<float> llr;
+    auto drain = [&] {
+        auto c = p.collect();
+        CHECK(c.has_value());
+        if (!c) return;
+        hard.insert(hard.end(), c->hard.begin(), c->hard.end());
+        llr.insert(llr.end(), c->llr.begin(), c->llr.end());
+        CHECK(p.release().has_value());
+    };
+    const size_t per = N + CP;
+    for (size_t first = 0; first < 10; first += 4) {               // 4 + 4 + 2 symbols through 2 slots
+        const size_t n = std::min<size_t>(4, 10 - first);
+        if (p.in_flight() == o.depth) drain();
+        auto buf = p.acquire();
+        CHECK(buf.has_value() && buf->size() == 4 * per);
+        std::copy(air.begin() + first * per, air.begin() + (first + n) * per, buf->begin());
+        CHECK(p.submit(n).has_value());
+    }
+    while (p.in_flight()) drain();
+    CHECK(hard == payload && hard == whole->hard);
+    CHECK(llr == whole->llr);
+    CHECK(!p.collect().has_value());                               // protocol errors are values
+    auto bad = sdrlib::pipe::create(sdrlib::pipe_options{.n_fft = 48});
+    CHECK(!bad.has_value() && bad.error() == "The sequence size must be of powers of 2");
+}
+
 int main(int argc, char** argv)
 {
     if (argc > 1 && std::strcmp(argv[1], "--expect-no-device") == 0) {
@@ -158,6 +204,7 @@ int main(int argc, char** argv)
     qam16_hello();
     app_tick();
     extras();
+    streaming_pipe();
     std::printf(g_failed ? "FAILED %d checks\n" : "ok: all drop-in checks passed\n", g_failed);
     return g_failed ? 1 : 0;
 }
