@@ -174,13 +174,15 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) tx_fused_kernel(const TxP
         fft_run<LOG2N>(x, lds, addr, tw);
 
         // ---- /N (fft.hpp:200-202), noise, store with cyclic prefix (ofdm.hpp:21) ----
-        constexpr float LEN = static_cast<float>(N);
+        // ifft2 divides by N (fft.hpp:200-202); N is a power of two, so the product with the exact
+        // reciprocal is the same correctly rounded value as the quotient, at a tenth of the cost
+        constexpr float INV_LEN = 1.0f / static_cast<float>(N);
         float2* dst = p.out + sym * out_stride;
         const uint32_t cp = p.cp;
         static_for<E>([&](auto M) {
             constexpr int m = M;
             const int n = A::out_reg(m) | addr.pos_last;
-            float2 v = make_float2(x[m].x / LEN, x[m].y / LEN);
+            float2 v = make_float2(x[m].x * INV_LEN, x[m].y * INV_LEN);
             float2 vcp = v;
             if constexpr (NOISE) {
                 // samples n and n + N/2 share one Philox block; the top index bit is a register bit
@@ -239,17 +241,20 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) mc_fused_kernel(const McP
     constexpr int DATA_BYTES = SYM_BYTES * SPW;
     constexpr int TW_BYTES = O::kMidCount * 8;
     constexpr int TIME_BYTES = N * 8 * SPW;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[DATA_BYTES + 2 * TW_BYTES + TIME_BYTES + 16];
-    float2* lds_time = reinterpret_cast<float2*>(lds + DATA_BYTES + 2 * TW_BYTES);
+    __shared__ __attribute__((aligned(16))) unsigned char lds[DATA_BYTES + TW_BYTES + TIME_BYTES + 16];
+    float2* lds_time = reinterpret_cast<float2*>(lds + DATA_BYTES + TW_BYTES);
 
     const int tid = threadIdx.x;
     const int slot = tid / TPS;
     const int t = tid % TPS;
     A addr;
     addr.init(t, slot, SYM_BYTES);
-    FftTwiddles<LOG2N> tw_inv, tw_fwd;
-    tw_inv.init(p.tw_inv, reinterpret_cast<float2*>(lds + DATA_BYTES), tid, addr);
-    tw_fwd.init(p.tw_fwd, reinterpret_cast<float2*>(lds + DATA_BYTES + TW_BYTES), tid, addr);
+    // One twiddle set serves both directions: the inverse transform runs on the forward table
+    // with conjugated butterflies (rx_fused.hpp, bfly<CONJ>).  That can differ from the true
+    // inverse table only in the sign of exact zeros, which no counter can see; it halves the
+    // twiddle registers of this register-bound kernel.
+    FftTwiddles<LOG2N> tw_fwd;
+    tw_fwd.init(p.tw_fwd, reinterpret_cast<float2*>(lds + DATA_BYTES), tid, addr);
     if constexpr (O::kMidCount > 0) __syncthreads();
 
     unsigned long long c_bit = 0, c_sym = 0, c_abs = 0, c_sign = 0, c_n = 0;
@@ -263,45 +268,79 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) mc_fused_kernel(const McP
         if (!active) sym = p.n_sym - 1;
         const unsigned long long g = p.first_symbol + sym;
 
+        const unsigned long long abs_before = c_abs;
         // ---- transmit: indices -> constellation -> IFFT -> /N -> + noise ----
         float2 x[E];
         for_each_tx_index<LOG2N, BPS, false>(p.seed, g, addr.in_thread, [&](auto M, uint32_t idx) {
             constexpr int m = M;
             x[m] = make_float2(level_of<MI>(idx >> MQ) * p.norm, level_of<MQ>(idx & ((1u << MQ) - 1u)) * p.norm);
         });
-        fft_run<LOG2N>(x, lds, addr, tw_inv);
-        constexpr float LEN = static_cast<float>(N);
+        fft_run<LOG2N, true>(x, lds, addr, tw_fwd);
+        // ifft2 divides by N (fft.hpp:200-202); N is a power of two, so the product with the exact
+        // reciprocal is the same correctly rounded value as the quotient, at a tenth of the cost
+        constexpr float INV_LEN = 1.0f / static_cast<float>(N);
         static_for<E>([&](auto M) {
             constexpr int m = M;
             const int n = A::out_reg(m) | addr.pos_last;
-            constexpr int top = A::out_reg(m) >> (LOG2N - 1);
-            const Philox4 b = noise_block(p.seed, g, static_cast<uint32_t>(n & (N / 2 - 1)));
-            const float2 nz = gaussian_pair(top ? b.v[2] : b.v[0], top ? b.v[3] : b.v[1], p.sigma);
-            lds_time[slot * N + n] = make_float2(x[m].x / LEN + nz.x, x[m].y / LEN + nz.y);
+            lds_time[slot * N + n] = make_float2(x[m].x * INV_LEN, x[m].y * INV_LEN);
         });
+        __syncthreads();
+        // Noise as a ROLLED loop over the symbol's N/2 Philox blocks (samples n and n + N/2 share
+        // one).  Fully unrolled, the sixteen independent Philox + Box-Muller chains drove the
+        // kernel to 256 + 160 registers and one wave per SIMD.
+#pragma unroll 1
+        for (int i = 0; i < E / 2; ++i) {
+            const int n = i * TPS + t;
+            const Philox4 b = noise_block(p.seed, g, static_cast<uint32_t>(n));
+            const float2 z0 = gaussian_pair(b.v[0], b.v[1], p.sigma);
+            const float2 z1 = gaussian_pair(b.v[2], b.v[3], p.sigma);
+            float2* lo = lds_time + slot * N + n;
+            float2* hi = lo + N / 2;
+            const float2 a0 = *lo, a1 = *hi;
+            *lo = make_float2(a0.x + z0.x, a0.y + z0.y);
+            *hi = make_float2(a1.x + z1.x, a1.y + z1.y);
+        }
         __syncthreads();
         // ---- receive: the CP would be dropped here (ofdm.hpp:41); its samples are never made ----
         static_for<E>([&](auto M) { constexpr int m = M; x[m] = lds_time[slot * N + (A::in_reg(m) | addr.in_thread)]; });
         fft_run<LOG2N>(x, lds, addr, tw_fwd);
 
-        for_each_tx_index<LOG2N, BPS, true>(p.seed, g, addr.pos_last, [&](auto M, uint32_t ref) {
-            constexpr int m = M;
-            float l[BPS];
-            const unsigned idx = demap_point<float, MI, MQ, true, true>(x[m].x, x[m].y, p.inorm, p.w0, l);
-            if (active) {
+        // Demapping and counting as ROLLED loops over LDS: thread t takes Philox block j*TPS + t,
+        // i.e. the eight subcarriers block + l*(N/8).  Unrolled in registers, sixteen interleaved
+        // demappers (2 x 2^(bps/2) distances each) needed 500+ registers at 64/256-QAM.
+        static_for<E>([&](auto M) { constexpr int m = M; lds_time[slot * N + (A::out_reg(m) | addr.pos_last)] = x[m]; });
+        __syncthreads();
+        unsigned n_bit = 0, n_sym_err = 0, n_sign = 0;              // per symbol and thread: <= 16 points x 10 bits
+#pragma unroll 1
+        for (int j = 0; j < E / 8; ++j) {
+            const int block = j * TPS + t;
+            const Philox4 r = tx_block(p.seed, g, static_cast<uint32_t>(block));
+#pragma unroll 1
+            for (int lane = 0; lane < 8; ++lane) {
+                const int pair = lane >> 1;
+                const uint32_t word = pair == 0 ? r.v[0] : pair == 1 ? r.v[1] : pair == 2 ? r.v[2] : r.v[3];
+                const uint32_t ref = ((word >> (16u * (lane & 1u))) & 0xFFFFu) & ((1u << BPS) - 1u);
+                const float2 y = lds_time[slot * N + block + lane * (N / 8)];
+                float l[BPS];
+                const unsigned idx = demap_point<float, MI, MQ, true, true>(y.x, y.y, p.inorm, p.w0, l);
                 const unsigned diff = ref ^ idx;
-                c_bit += __popc(diff);
-                c_sym += (diff != 0);
-                c_n += 1;
+                n_bit += __popc(diff);
+                n_sym_err += (diff != 0);
+                unsigned two = 0;
                 static_for<BPS>([&](auto B) {
                     constexpr int b = B;
                     float a = fabsf(l[b]) * 1024.0f;
                     a = (a < 1073741824.0f) ? a : 1073741824.0f;
-                    c_abs += static_cast<unsigned long long>(static_cast<long long>(a));
-                    c_sign += (((ref >> (BPS - 1 - b)) & 1u) != (l[b] < 0.0f ? 1u : 0u));
+                    // a in [0, 2^30]: the 32-bit truncation is the 64-bit one; two of them fit 32 bits
+                    if constexpr (b % 2 == 0) two = static_cast<unsigned>(static_cast<int>(a));
+                    else { c_abs += two + static_cast<unsigned>(static_cast<int>(a)); two = 0; }
+                    n_sign += (((ref >> (BPS - 1 - b)) & 1u) != (l[b] < 0.0f ? 1u : 0u));
                 });
+                c_abs += two;
             }
-        });
+        }
+        if (active) { c_bit += n_bit; c_sym += n_sym_err; c_sign += n_sign; c_n += E; }
+        else c_abs = abs_before;
         __syncthreads();
     }
 

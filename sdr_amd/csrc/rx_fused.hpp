@@ -164,10 +164,21 @@ struct PlanOps {
     }
 };
 
+// CONJ: rotate by conj(w).  a - b*(-c) and a + b*c are the same IEEE operation, and the inverse
+// table is the conjugate of the forward one except for the sign of the zero imaginary part of
+// its W = 1 entries (checked on the host tables), so an inverse transform run this way on the
+// forward table can differ from the true one only in the sign of exact zeros.
+template <bool CONJ = false>
 __device__ __forceinline__ void bfly(float2& even, float2& odd, const float2 w)
 {
-    const float tr = odd.x * w.x - odd.y * w.y;
-    const float ti = odd.x * w.y + odd.y * w.x;
+    float tr, ti;
+    if constexpr (CONJ) {
+        tr = odd.x * w.x + odd.y * w.y;
+        ti = odd.y * w.x - odd.x * w.y;
+    } else {
+        tr = odd.x * w.x - odd.y * w.y;
+        ti = odd.x * w.y + odd.y * w.x;
+    }
     const float ar = even.x + tr, ai = even.y + ti;
     const float br = even.x - tr, bi = even.y - ti;
     even.x = ar; even.y = ai;
@@ -255,7 +266,7 @@ struct FftTwiddles {
 // All stages of the network on one symbol: x enters in the first-pass register pattern and
 // leaves in the last-pass pattern (natural order bins).  Contains the workgroup barriers of the
 // exchanges; the caller barriers before the exchange region is reused.
-template <int LOG2N>
+template <int LOG2N, bool CONJ = false>
 __device__ __forceinline__ void fft_run(float2 (&x)[PlanOps<LOG2N>::kE], unsigned char* lds_data, const FftAddr<LOG2N>& a, const FftTwiddles<LOG2N>& w)
 {
     using O = PlanOps<LOG2N>;
@@ -267,7 +278,7 @@ __device__ __forceinline__ void fft_run(float2 (&x)[PlanOps<LOG2N>::kE], unsigne
         static_for<E / 2>([&](auto H) {
             constexpr int m0 = O::insert_zero(H, bi), m1 = m0 | (1 << bi);
             constexpr int j = O::reg_pos(0, m0) & ((1 << c) - 1);
-            bfly(x[m0], x[m1], w.first[(1 << c) - 1 + j]);
+            bfly<CONJ>(x[m0], x[m1], w.first[(1 << c) - 1 + j]);
         });
     });
     static_for<E>([&](auto M) { constexpr int m = M; *reinterpret_cast<float2*>(lds_data + a.wr0 + O::reg_addr(0, 0, m)) = x[m]; });
@@ -280,7 +291,7 @@ __device__ __forceinline__ void fft_run(float2 (&x)[PlanOps<LOG2N>::kE], unsigne
             static_for<E / 2>([&](auto H) {
                 constexpr int m0 = O::insert_zero(H, bi), m1 = m0 | (1 << bi);
                 constexpr int jm = O::reg_pos(1, m0) & ((1 << c) - 1);
-                bfly(x[m0], x[m1], w.mid[(1 << c) - 1 - O::kMidFirst + jm + a.mid_jt]);
+                bfly<CONJ>(x[m0], x[m1], w.mid[(1 << c) - 1 - O::kMidFirst + jm + a.mid_jt]);
             });
         });
         __syncthreads();   // all reads of exchange 0 done before the region is rewritten
@@ -295,7 +306,7 @@ __device__ __forceinline__ void fft_run(float2 (&x)[PlanOps<LOG2N>::kE], unsigne
         constexpr int mask = O::last_low_mask(c);
         static_for<E / 2>([&](auto H) {
             constexpr int m0 = O::insert_zero(H, bi), m1 = m0 | (1 << bi);
-            bfly(x[m0], x[m1], w.last[O::last_tw_offset(s) + O::pext(m0, mask)]);
+            bfly<CONJ>(x[m0], x[m1], w.last[O::last_tw_offset(s) + O::pext(m0, mask)]);
         });
     });
 }
