@@ -18,6 +18,7 @@
 namespace sdr {
 
 struct TxParams {
+    uint32_t vec16;              // output rows allow 16-byte stores (even cp, aligned base)
     const float2* freq;          // n_sym x N bins (SRC_GLOBAL) or null
     const float2* tw_inv;        // N-1 inverse twiddles
     const float2* chan;          // n_sets x N or null (generator only)
@@ -46,6 +47,8 @@ struct McParams {
     float inorm;
     uint32_t groups_per_wg;
 };
+
+__device__ __forceinline__ int slot_of(unsigned tid, int tps) { return static_cast<int>(tid) / tps; }
 
 // integer grid level of Gray code g on an axis with M bits, as float
 template <int M>
@@ -110,8 +113,10 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) tx_fused_kernel(const TxP
     constexpr int DATA_BYTES = SYM_BYTES * SPW;
     constexpr int TW_BYTES = O::kMidCount * 8;
     constexpr int IDX_BYTES = SRC_GLOBAL ? 0 : N * SPW;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[DATA_BYTES + TW_BYTES + IDX_BYTES + 16];
+    constexpr int TIME_OFF = (DATA_BYTES + TW_BYTES + IDX_BYTES + 15) & ~15;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[TIME_OFF + N * 8 * SPW + 16];
     unsigned char* lds_idx = lds + DATA_BYTES + TW_BYTES;
+    float2* lds_time = reinterpret_cast<float2*>(lds + TIME_OFF) + slot_of(threadIdx.x, TPS) * N;   // this symbol's time-domain samples
 
     const int tid = threadIdx.x;
     const int slot = tid / TPS;
@@ -178,33 +183,53 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) tx_fused_kernel(const TxP
         // reciprocal is the same correctly rounded value as the quotient, at a tenth of the cost
         constexpr float INV_LEN = 1.0f / static_cast<float>(N);
         float2* dst = p.out + sym * out_stride;
-        const uint32_t cp = p.cp;
+        const int cp = static_cast<int>(p.cp);
+        // The symbol is assembled in LDS in natural order, so that the noise is a rolled loop
+        // (unrolled, sixteen Philox + Box-Muller chains per thread took 250 + 160 registers) and
+        // the stores are contiguous over the lanes.
         static_for<E>([&](auto M) {
             constexpr int m = M;
-            const int n = A::out_reg(m) | addr.pos_last;
-            float2 v = make_float2(x[m].x * INV_LEN, x[m].y * INV_LEN);
-            float2 vcp = v;
-            if constexpr (NOISE) {
-                // samples n and n + N/2 share one Philox block; the top index bit is a register bit
-                constexpr int top = A::out_reg(m) >> (LOG2N - 1);
-                const Philox4 b = noise_block(p.seed, g, static_cast<uint32_t>(n & (N / 2 - 1)));
-                const float2 nz = gaussian_pair(top ? b.v[2] : b.v[0], top ? b.v[3] : b.v[1], p.sigma);
-                v.x = v.x + nz.x;
-                v.y = v.y + nz.y;
-            }
-            if (active) {
-                dst[cp + n] = v;
-                if (n + static_cast<int>(cp) >= N) {
-                    const uint32_t c = static_cast<uint32_t>(n) + cp - N;
-                    if constexpr (NOISE) {
-                        const float2 nz = cp_noise(p.seed, g, c, p.sigma);
-                        vcp.x = vcp.x + nz.x;
-                        vcp.y = vcp.y + nz.y;
-                    }
-                    dst[c] = vcp;
-                }
-            }
+            lds_time[A::out_reg(m) | addr.pos_last] = make_float2(x[m].x * INV_LEN, x[m].y * INV_LEN);
         });
+        __syncthreads();
+        // cyclic prefix first (ofdm.hpp:21 copies the clean tail; its noise is a stream of its own)
+        if (active) {
+#pragma unroll 1
+            for (int c = t; c < cp; c += TPS) {
+                float2 v = lds_time[N - cp + c];
+                if constexpr (NOISE) {
+                    const float2 nz = cp_noise(p.seed, g, static_cast<uint32_t>(c), p.sigma);
+                    v.x = v.x + nz.x;
+                    v.y = v.y + nz.y;
+                }
+                dst[c] = v;
+            }
+        }
+        if constexpr (NOISE) {
+            __syncthreads();                                        // prefix read the clean tail
+#pragma unroll 1
+            for (int i = 0; i < E / 2; ++i) {                       // samples n and n + N/2 share one Philox block
+                const int n = i * TPS + t;
+                const Philox4 b = noise_block(p.seed, g, static_cast<uint32_t>(n));
+                const float2 z0 = gaussian_pair(b.v[0], b.v[1], p.sigma);
+                const float2 z1 = gaussian_pair(b.v[2], b.v[3], p.sigma);
+                const float2 a0 = lds_time[n], a1 = lds_time[n + N / 2];
+                lds_time[n] = make_float2(a0.x + z0.x, a0.y + z0.y);
+                lds_time[n + N / 2] = make_float2(a1.x + z1.x, a1.y + z1.y);
+            }
+            __syncthreads();
+        }
+        if (active) {
+            if (p.vec16) {                                           // even cp, 16-byte aligned output: two samples per lane
+                const float4* src4 = reinterpret_cast<const float4*>(lds_time);
+                float4* dst4 = reinterpret_cast<float4*>(dst + cp);
+#pragma unroll
+                for (int i = 0; i < E / 2; ++i) dst4[i * TPS + t] = src4[i * TPS + t];
+            } else {
+#pragma unroll
+                for (int i = 0; i < E; ++i) dst[cp + i * TPS + t] = lds_time[i * TPS + t];
+            }
+        }
         if constexpr (!SRC_GLOBAL) {
             if (p.tx_bits) {
                 __syncthreads();
@@ -374,6 +399,7 @@ int launch_tx_fused(sdr_ctx* ctx, const TxParams& p)
     if (blocks > 0x7FFFFFFFull) return fail(SDR_ERR_UNSUPPORTED, "batch too large for one launch");
     TxParams q = p;
     q.groups_per_wg = static_cast<uint32_t>(per_wg);
+    q.vec16 = (p.cp % 2 == 0) && (reinterpret_cast<uintptr_t>(p.out) % 16 == 0);
     hipLaunchKernelGGL((tx_fused_kernel<LOG2N, MI, MQ, SRC_GLOBAL, NOISE>), dim3(static_cast<unsigned>(blocks)), dim3(O::kWG), 0, ctx->stream, q);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(e, "tx_fused_kernel launch");

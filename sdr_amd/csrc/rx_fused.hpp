@@ -384,8 +384,18 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) SDR_WAVES_ATTR rx_fused_k
     constexpr int STG_STRIDE = stage_stride_bytes(CHUNK);
     constexpr int STG_WAVE_BYTES = STAGE ? 64 * STG_STRIDE : 0;
     constexpr int STG_BYTES = STG_WAVE_BYTES * (O::kWG / 64);
-    constexpr int STG_OFF = (DATA_BYTES + TW_BYTES + IDX_BYTES + REF_BYTES + 15) & ~15;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[STG_OFF + STG_BYTES + 16];
+    // The staging strips reuse the exchange region when they fit: it is dead between the last
+    // exchange read and the next symbol's first exchange write.  LDS, not registers, bounds the
+    // resident waves of this kernel (20 KB per one-wave workgroup = 7 waves per CU at N = 1024;
+    // 12-16 with the alias -- which measured neutral: the kernel sits at the memory system's ceiling).
+#ifdef SDR_NO_STG_ALIAS
+    constexpr bool STG_ALIAS = false;
+#else
+    constexpr bool STG_ALIAS = STAGE && STG_BYTES <= DATA_BYTES && O::kWG == 64;   // multi-wave: the barrier it needs costs more (measured)
+#endif
+    constexpr int STG_OFF = STG_ALIAS ? 0 : (DATA_BYTES + TW_BYTES + IDX_BYTES + REF_BYTES + 15) & ~15;
+    constexpr int LDS_BYTES = STG_ALIAS ? DATA_BYTES + TW_BYTES + IDX_BYTES + REF_BYTES : STG_OFF + STG_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES + 16];
     unsigned char* lds_data = lds;
     unsigned char* lds_idx = lds + DATA_BYTES + TW_BYTES;
     [[maybe_unused]] unsigned char* lds_ref = lds + DATA_BYTES + TW_BYTES + IDX_BYTES;
@@ -422,7 +432,11 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) SDR_WAVES_ATTR rx_fused_k
                 dst[q] = src[idx0];
             } else {
                 // register bit kR[0] is the group bit: adjacent input samples
+#ifdef SDR_NT_LOADS
+                const sdr_v4f v = __builtin_nontemporal_load(reinterpret_cast<const sdr_v4f*>(src + idx0));
+#else
                 const float4 v = *reinterpret_cast<const float4*>(src + idx0);
+#endif
                 dst[q] = make_float2(v.x, v.y);
                 dst[q | (1 << P::kR[0])] = make_float2(v.z, v.w);
             }
