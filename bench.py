@@ -77,25 +77,26 @@ def make_inputs(ctx, torch, n_fft, cp, bps, n_sym, ebn0_db, with_eq, seed, first
     return rx, eq, wgt, w0, per
 
 
-def cpu_baseline(n_fft, cp, bps, budget_s=12.0):
+def cpu_baseline(n_fft, cp, bps, budget_s=12.0, threads=1):
     """The CPU oracle (port of the reference path: ofdm::rx + nearest, plus the same LLR
-    definition), one thread as the reference runs, on a bounded sample of the same workload."""
+    definition) on a bounded sample of the same workload.  threads=1 is how the reference runs
+    (its OpenMP pragma is dead); threads>1 splits the symbols over host threads."""
     import numpy as np
     from oracle import binding as oracle
     from sdr_amd.link import noise_sigma, llr_weight
-    n_s = max(64, min(2048, (1 << 21) // n_fft))
+    n_s = max(64, min(2048, (1 << 21) // n_fft)) * (1 if threads == 1 else 4)
     rx, _ = oracle.link_generate(n_fft, cp, bps, 2, 0, n_s, np.float32(noise_sigma(n_fft, bps, 12.0)))
     w = np.float32(llr_weight(bps, 12.0))
     oracle.demod(rx[:8], n_fft, cp, bps, weight=w, want_fft=False)
     done, t0 = 0, time.perf_counter()
     while True:
-        oracle.demod(rx, n_fft, cp, bps, weight=w, want_fft=False)
+        oracle.demod(rx, n_fft, cp, bps, weight=w, want_fft=False, threads=threads)
         done += n_s
         dt = time.perf_counter() - t0
         if dt >= budget_s:
             break
-    return {"value": done / dt, "unit": "OFDM symbols/s", "cores": 1, "kind": "port",
-            "sample": f"{done} symbols ({n_s}-symbol batch x {done // n_s} passes) of FFT-{n_fft}/{bps}-bit LLR+hard demod in {dt:.1f} s, 1 thread of {os.cpu_count()} host CPUs"}
+    return {"value": done / dt, "unit": "OFDM symbols/s", "cores": threads, "kind": "port",
+            "sample": f"{done} symbols ({n_s}-symbol batch x {done // n_s} passes) of FFT-{n_fft}/{bps}-bit LLR+hard demod in {dt:.1f} s, {threads} thread(s) of {os.cpu_count()} host CPUs"}
 
 
 def time_workload(ctx, torch, dist, name, steps, warmup, world, rank, n_sym_override=None):
@@ -192,6 +193,10 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
         cpu = cpu_baseline(main_res["n_fft"], main_res["cp"], main_res["bps"])
+        # the box's CPU share for one GPU is what OMP_NUM_THREADS says (16), not os.cpu_count()
+        share = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or (os.cpu_count() or 1), os.cpu_count() or 1, 64))
+        if share > 1:
+            extra["cpu_baseline_all_threads"] = cpu_baseline(main_res["n_fft"], main_res["cp"], main_res["bps"], budget_s=6.0, threads=share)
     if rank == 0:
         n_fft, bps = main_res["n_fft"], main_res["bps"]
         line = {

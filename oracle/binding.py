@@ -152,8 +152,9 @@ def zf_taps(bps, chan, inv_n0):
     return taps, wgt
 
 
-def demod(rx, n_fft, cp, bps, eq=None, weight=1.0, sym_per_set=0, want_fft=True, want_llr=True, want_hard=True):
-    """Fused receive path on the CPU.  Returns dict(fft, llr, hard)."""
+def demod(rx, n_fft, cp, bps, eq=None, weight=1.0, sym_per_set=0, want_fft=True, want_llr=True, want_hard=True, threads=1):
+    """Fused receive path on the CPU.  Returns dict(fft, llr, hard).  threads > 1 splits the symbols
+    over host threads (same results; the reference itself runs on one)."""
     rx = _c(rx, np.complex64).ravel()
     n_sym = rx.size // (n_fft + cp)
     fft = np.zeros((n_sym, n_fft), dtype=np.complex64) if want_fft else None
@@ -162,8 +163,8 @@ def demod(rx, n_fft, cp, bps, eq=None, weight=1.0, sym_per_set=0, want_fft=True,
     eqa = _c(eq, np.complex64).ravel() if eq is not None else None
     wt = _c(weight, np.float32).ravel() if isinstance(weight, np.ndarray) else None
     w0 = 0.0 if wt is not None else float(weight)
-    rc = lib().orc_demod_c32(c_uint32(n_fft), c_uint32(cp), c_int(bps), c_size_t(n_sym), c_uint32(sym_per_set),
-                             _p(rx), _p(eqa), _p(wt), c_float(w0), _p(fft), _p(llr), _p(hard))
+    rc = lib().orc_demod_c32_threads(ctypes.c_uint(threads), c_uint32(n_fft), c_uint32(cp), c_int(bps), c_size_t(n_sym), c_uint32(sym_per_set),
+                                     _p(rx), _p(eqa), _p(wt), c_float(w0), _p(fft), _p(llr), _p(hard))
     assert rc == 0, rc
     return {"fft": fft, "llr": llr, "hard": hard}
 

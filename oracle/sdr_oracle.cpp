@@ -18,11 +18,13 @@
 //
 // All citations are path:line relative to /root/reference.
 
+#include <algorithm>
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
 #include <cstring>
 #include <limits>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -679,6 +681,40 @@ int orc_demod_c32(std::uint32_t n_fft, std::uint32_t cp, int bps, std::size_t n_
                 stream_put_clipped(hard_out, pos, bps, idx[k], (total_bits / 8) * 8);
             }
     }
+    return 0;
+}
+
+// The same over n_threads host threads, symbols split into contiguous ranges (symbols are
+// independent, lib/inc/ofdm.hpp:37-43 keeps no state; SURVEY.md 8(d) CPU baseline (ii)).  The
+// reference itself is single-threaded (its OpenMP pragma, fft.hpp:119, is dead).  Needs
+// n_fft*bps to be a whole number of bytes so that the ranges' hard bits do not share a byte.
+int orc_demod_c32_threads(unsigned n_threads, std::uint32_t n_fft, std::uint32_t cp, int bps, std::size_t n_sym, std::uint32_t sym_per_set,
+                          const float* rx, const float* eq, const float* wgt, float w0,
+                          float* fft_out, float* llr_out, std::uint8_t* hard_out)
+{
+    if (n_threads <= 1 || n_sym < 2 * n_threads) return orc_demod_c32(n_fft, cp, bps, n_sym, sym_per_set, rx, eq, wgt, w0, fft_out, llr_out, hard_out);
+    const std::size_t sym_bits = static_cast<std::size_t>(n_fft) * static_cast<std::size_t>(bps);
+    if (sym_bits % 8 != 0) return 1;
+    const std::size_t unit = sym_per_set ? sym_per_set : 1;          // ranges start on a set boundary
+    const std::size_t units = (n_sym + unit - 1) / unit;
+    std::vector<std::thread> pool;
+    std::vector<int> rc(n_threads, 0);
+    for (unsigned t = 0; t < n_threads; ++t) {
+        const std::size_t first = std::min(n_sym, (units * t / n_threads) * unit);
+        const std::size_t last = std::min(n_sym, (units * (t + 1) / n_threads) * unit);
+        if (first >= last) continue;
+        pool.emplace_back([=, &rc] {
+            const std::size_t set0 = sym_per_set ? first / sym_per_set : 0;
+            rc[t] = orc_demod_c32(n_fft, cp, bps, last - first, sym_per_set,
+                                  rx + 2 * first * (static_cast<std::size_t>(n_fft) + cp),
+                                  eq ? eq + 2 * set0 * n_fft : nullptr, wgt ? wgt + set0 * n_fft : nullptr, w0,
+                                  fft_out ? fft_out + 2 * first * n_fft : nullptr,
+                                  llr_out ? llr_out + first * sym_bits : nullptr,
+                                  hard_out ? hard_out + first * sym_bits / 8 : nullptr);
+        });
+    }
+    for (auto& th : pool) th.join();
+    for (int r : rc) if (r) return r;
     return 0;
 }
 

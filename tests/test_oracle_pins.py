@@ -228,3 +228,18 @@ def test_golden_vectors(oracle):
     rx, bits = oracle.link_generate(64, 16, 2, 1, 0, 3, 0.05)
     assert np.array_equal(rx, g["link_rx_64_qpsk"]) and np.array_equal(bits, g["link_bits_64_qpsk"])
     assert np.array_equal(oracle.link_ber(1024, 256, 4, 2, 28, 2, 0.012, 9.0), g["link_ber_1024_16qam"])
+
+
+def test_threaded_demod_equals_single_thread(oracle):
+    """bench.py's all-threads CPU leg: symbols split over host threads, same outputs."""
+    rng = np.random.default_rng(3)
+    n, cp, bps, n_sym, per = 64, 16, 6, 45, 7
+    n_sets = (n_sym + per - 1) // per
+    rx, _ = oracle.link_generate(n, cp, bps, 9, 0, n_sym, np.float32(0.02))
+    eq = (rng.standard_normal((n_sets, n)) + 1j * rng.standard_normal((n_sets, n))).astype(np.complex64)
+    wgt = rng.random((n_sets, n), dtype=np.float32)
+    one = oracle.demod(rx, n, cp, bps, eq=eq, weight=wgt, sym_per_set=per)
+    for threads in (2, 3, 8):
+        many = oracle.demod(rx, n, cp, bps, eq=eq, weight=wgt, sym_per_set=per, threads=threads)
+        for key in ("fft", "llr", "hard"):
+            assert np.array_equal(one[key], many[key]), (threads, key)
