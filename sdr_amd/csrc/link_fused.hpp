@@ -255,8 +255,14 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) tx_fused_kernel(const TxP
     }
 }
 
+#ifdef SDR_MC_WPE
+#define SDR_MC_ATTR __attribute__((amdgpu_waves_per_eu(SDR_MC_WPE)))
+#else
+#define SDR_MC_ATTR
+#endif
+
 template <int LOG2N, int MI, int MQ>
-__global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) mc_fused_kernel(const McParams p)
+__global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) SDR_MC_ATTR mc_fused_kernel(const McParams p)
 {
     using O = PlanOps<LOG2N>;
     using A = FftAddr<LOG2N>;

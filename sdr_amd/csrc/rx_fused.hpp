@@ -681,36 +681,58 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) SDR_WAVES_ATTR rx_fused_k
     }
 }
 
+// Tuning knobs, read from the environment once per process (measurement aids; the defaults are
+// what the benchmarks and tests run):
+//   SDR_GROUPS_PER_WG  symbol groups per workgroup (0 = one resident grid striding over the batch)
+//   SDR_XCD_WINDOW     window of the XCD-aware workgroup-id permutation (0 = off)
+//   SDR_DEBUG          print each instantiation's launch shape once
+struct RxTuning {
+    long groups_per_wg = -1;      // -1: default
+    long xcd_window = 4096;
+    bool debug = false;
+    RxTuning()
+    {
+        if (const char* v = getenv("SDR_GROUPS_PER_WG")) groups_per_wg = atol(v);
+        if (const char* v = getenv("SDR_XCD_WINDOW")) xcd_window = atol(v) & ~7L;
+        debug = getenv("SDR_DEBUG") != nullptr;
+    }
+};
+inline const RxTuning& rx_tuning()
+{
+    static const RxTuning t;      // C++11: initialised once, thread-safe
+    return t;
+}
+
 template <int LOG2N, int MI, int MQ, bool FULL, bool EQ>
 int launch_rx_fused(sdr_ctx* ctx, const RxParams& p)
 {
     using O = PlanOps<LOG2N>;
     auto kern = rx_fused_kernel<LOG2N, MI, MQ, FULL, EQ>;
-    static int blocks_per_cu = 0;
-    if (blocks_per_cu == 0) {
-        int nb = 0;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, O::kWG, 0);
-        if (e != hipSuccess) return fail_hip(e, "hipOccupancyMaxActiveBlocksPerMultiprocessor");
-        blocks_per_cu = nb > 0 ? nb : 1;
-        if (getenv("SDR_DEBUG")) fprintf(stderr, "[sdr] rx_fused<%d,%d,%d,%d,%d>: %d threads/WG, %d WG/CU, %d CUs\n", LOG2N, MI, MQ, int(FULL), int(EQ), O::kWG, blocks_per_cu, ctx->num_cu);
-    }
+    const RxTuning& tune = rx_tuning();
     const unsigned long long n_groups = (p.n_sym + O::kSPW - 1) / O::kSPW;
     // Each workgroup takes a run of consecutive symbol groups.  Short runs (many workgroups, the
     // hardware dispatcher balancing them) measured faster than a resident grid striding over the
     // batch; the per-workgroup twiddle set-up is amortised over the run.
     unsigned long long per_wg = p.counters ? 8 : 2;              // counting ends every workgroup with atomics: longer runs
-    if (const char* ov = getenv("SDR_GROUPS_PER_WG")) per_wg = static_cast<unsigned long long>(atol(ov));   // tuning knob; 0 = resident grid
-    if (per_wg == 0) {
-        const unsigned long long resident = static_cast<unsigned long long>(ctx->num_cu) * blocks_per_cu;
-        per_wg = (n_groups + resident - 1) / resident;
+    if (tune.groups_per_wg >= 0) per_wg = static_cast<unsigned long long>(tune.groups_per_wg);
+    if (per_wg == 0 || tune.debug) {
+        int nb = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, O::kWG, 0);
+        if (e != hipSuccess) return fail_hip(e, "hipOccupancyMaxActiveBlocksPerMultiprocessor");
+        if (nb < 1) nb = 1;
+        if (tune.debug) fprintf(stderr, "[sdr] rx_fused<%d,%d,%d,%d,%d>: %d threads/WG, %d WG/CU, %d CUs\n", LOG2N, MI, MQ, int(FULL), int(EQ), O::kWG, nb, ctx->num_cu);
+        if (per_wg == 0) {
+            const unsigned long long resident = static_cast<unsigned long long>(ctx->num_cu) * nb;
+            per_wg = (n_groups + resident - 1) / resident;
+        }
     }
     if (per_wg > 0xFFFFFFFFull) per_wg = 0xFFFFFFFFull;
-    unsigned long long blocks = (n_groups + per_wg - 1) / per_wg;
+    if (per_wg == 0) per_wg = 1;
+    const unsigned long long blocks = (n_groups + per_wg - 1) / per_wg;
     if (blocks > 0x7FFFFFFFull) return fail(SDR_ERR_UNSUPPORTED, "batch too large for one launch");
     RxParams q = p;
     q.groups_per_wg = static_cast<uint32_t>(per_wg);
-    q.xcd_window = 4096;
-    if (const char* ov = getenv("SDR_XCD_WINDOW")) q.xcd_window = static_cast<uint32_t>(atol(ov)) & ~7u;   // tuning knob
+    q.xcd_window = static_cast<uint32_t>(tune.xcd_window > 0 ? tune.xcd_window : 0);
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(O::kWG), 0, ctx->stream, q);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(e, "rx_fused_kernel launch");
