@@ -418,3 +418,34 @@ def test_pipe_protocol_errors(ctx):
             pipe.submit(9)                                                              # more than a slot holds
         pipe.submit(1)
         assert pipe.in_flight() == 2
+
+
+# ---- argument errors surface as values, never as faults --------------------------------------------
+def test_c_abi_argument_errors(ctx):
+    import ctypes
+    from sdr_amd import capi
+    lib, h = ctx.lib, ctx._h
+    rx = torch.zeros(4 * 80, dtype=torch.complex64, device="cuda")
+    llr = torch.zeros(4 * 64 * 4, dtype=torch.float32, device="cuda")
+
+    def args(**kw):
+        a = capi.DemodArgs()
+        a.struct_size = ctypes.sizeof(capi.DemodArgs)
+        a.n_fft, a.cp, a.mod, a.n_sym = 64, 16, 4, 4
+        a.d_rx, a.d_llr = rx.data_ptr(), llr.data_ptr()
+        for k, v in kw.items():
+            setattr(a, k, v)
+        return a
+
+    assert lib.sdr_ofdm_demod_c32(h, ctypes.byref(args())) == capi.SDR_OK
+    assert lib.sdr_ofdm_demod_c32(h, None) == capi.SDR_ERR_INVALID
+    assert lib.sdr_ofdm_demod_c32(h, ctypes.byref(args(struct_size=8))) == capi.SDR_ERR_INVALID
+    assert "struct_size" in capi.last_error()
+    assert lib.sdr_ofdm_demod_c32(h, ctypes.byref(args(mod=3))) == capi.SDR_ERR_INVALID
+    assert lib.sdr_ofdm_demod_c32(h, ctypes.byref(args(n_fft=48))) == capi.SDR_ERR_NOT_POW2
+    assert capi.last_error() == "The sequence size must be of powers of 2"
+    assert lib.sdr_ofdm_demod_c32(h, ctypes.byref(args(d_rx=None))) == capi.SDR_ERR_INVALID
+    cnt = torch.zeros(8, dtype=torch.int64, device="cuda")
+    assert lib.sdr_ofdm_demod_c32(h, ctypes.byref(args(d_counters=cnt.data_ptr()))) == capi.SDR_ERR_INVALID   # counters without reference bits
+    assert lib.sdr_ofdm_demod_c32(h, ctypes.byref(args(n_sym=0))) == capi.SDR_OK                                # empty batch: nothing to do
+    torch.cuda.synchronize()
