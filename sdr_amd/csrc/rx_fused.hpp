@@ -500,7 +500,7 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) SDR_WAVES_ATTR rx_fused_k
         // own samples) whose values are never used.
         [[maybe_unused]] float2 eqv[EQ ? E : 1];
         [[maybe_unused]] float wv[EQ ? E : 1];
-        constexpr bool PREFETCH_TAPS = EQ && DEMAP && !FULL;       // FULL has no registers to spare: it reads taps in place
+        constexpr bool PREFETCH_TAPS = EQ && DEMAP;
         [[maybe_unused]] size_t tap_set = 0;
         if constexpr (EQ && DEMAP) tap_set = p.sym_per_set ? static_cast<size_t>(sym / p.sym_per_set) : 0;
         if constexpr (PREFETCH_TAPS) {
