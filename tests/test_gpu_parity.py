@@ -16,7 +16,7 @@ TOL = 1e-4
 
 
 def dev(a):
-    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    return torch.from_numpy(np.array(a, copy=True, order="C")).cuda()
 
 
 def rel_err(a, ref):
@@ -367,6 +367,37 @@ def test_full_size_two_paths_agree(ctx, n, cp, bps, ebn0):
     sign_bits = (llr_only < 0).reshape(-1, 8).to(torch.uint8)
     packed = (sign_bits * torch.tensor([128, 64, 32, 16, 8, 4, 2, 1], dtype=torch.uint8, device="cuda")).sum(dim=1).to(torch.uint8)
     assert int(lut[torch.bitwise_xor(packed, bits).long()].sum().item()) == c1[6].item()
+
+
+def test_full_size_equalised_round_trip(ctx):
+    """BASELINE configs[2] shape (FFT-2048, 64-QAM, one channel set per 14-symbol frame) at one
+    resident chunk: generate through a random channel -> ZF taps -> fused receive.  Properties
+    that need no oracle: at high SNR nearly every bit comes back; the kernel's own counters equal
+    a recount of its hard bits; the tap-prefetching LLR-only instantiation and the all-outputs
+    instantiation write identical LLRs; splitting the chunk at a frame boundary changes nothing."""
+    from sdr_amd.link import noise_sigma
+    n, cp, bps, per = 2048, 512, 6, 14
+    n_sym = per * 2340                                   # 32760 symbols, whole frames
+    g = torch.Generator(device="cuda").manual_seed(11)
+    n_sets = n_sym // per
+    h = torch.complex(torch.randn((n_sets, n), device="cuda", generator=g), torch.randn((n_sets, n), device="cuda", generator=g)) * (0.5 ** 0.5)
+    h = torch.where(h.abs() < 0.25, h + 0.5, h).to(torch.complex64).contiguous()     # keep |H| away from 0
+    ebn0 = 45.0
+    rx, bits = ctx.link_generate(n, cp, bps, seed=3, first_symbol=0, n_sym=n_sym, sigma=noise_sigma(n, bps, ebn0), chan=h, sym_per_set=per)
+    taps, wgt = ctx.zf_taps(h.view(-1), bps, bps * 10 ** (ebn0 / 10))
+    cnt = torch.zeros(8, dtype=torch.int64, device="cuda")
+    full = ctx.demod(rx, n, cp, bps, eq=taps, llr_weight=wgt, sym_per_set=per, want_hard=True, ref_hard=bits, counters=cnt)
+    c = cnt.tolist()
+    assert c[1] == n_sym * n * bps and c[4] == n_sym
+    assert c[0] < 1e-4 * c[1]                                            # ZF at 45 dB: a handful of deep-fade errors at most
+    lut = torch.tensor([bin(i).count("1") for i in range(256)], dtype=torch.int64, device="cuda")
+    assert int(lut[torch.bitwise_xor(full.hard, bits).long()].sum().item()) == c[0]
+    llr_only = ctx.demod(rx, n, cp, bps, eq=taps, llr_weight=wgt, sym_per_set=per).llr
+    assert torch.equal(llr_only, full.llr)
+    cut = per * 1000
+    a = ctx.demod(rx[:cut], n, cp, bps, eq=taps, llr_weight=wgt, sym_per_set=per).llr
+    b = ctx.demod(rx[cut:], n, cp, bps, eq=taps.view(n_sets, n)[cut // per:], llr_weight=wgt.view(n_sets, n)[cut // per:], sym_per_set=per).llr
+    assert torch.equal(torch.cat([a, b]), full.llr)
 
 
 # ---- streaming ingest ----------------------------------------------------------------------------
