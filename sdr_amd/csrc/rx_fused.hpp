@@ -459,6 +459,10 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) SDR_WAVES_ATTR rx_fused_k
     const unsigned long long grp_begin = wg * p.groups_per_wg;
     const unsigned long long grp_end = (grp_begin + p.groups_per_wg < n_groups) ? grp_begin + p.groups_per_wg : n_groups;
     float2 x[E];
+    constexpr bool PREFETCH_TAPS = EQ && DEMAP;
+    [[maybe_unused]] float2 eqv[EQ ? E : 1];
+    [[maybe_unused]] float wv[EQ ? E : 1];
+    [[maybe_unused]] size_t held_set = ~static_cast<size_t>(0);     // set whose taps the registers hold
 #ifdef SDR_PREFETCH
     float2 xn[E];
     if (grp_begin < grp_end) load_symbol(grp_begin, xn);
@@ -468,8 +472,43 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) SDR_WAVES_ATTR rx_fused_k
         const bool active = sym < p.n_sym;
         if (!active) sym = p.n_sym - 1;
 
+        // Taps and weights of this thread's output bins, kept in registers for as long as the
+        // run stays inside one set (a workgroup's symbols are consecutive, a set spans
+        // sym_per_set of them).  When the set changes they are requested FIRST, ahead of the
+        // samples: vector-memory results return in order, so the wait for the samples (which the
+        // transform needs anyway) covers them and nothing is left to wait for in the epilogue.
+        // A load under a run-time branch placed AFTER the samples would make the compiler's
+        // wait-count bookkeeping fall back to "wait for everything" in front of the transform.
+        // A missing array is replaced by an always-valid dummy source (this symbol's own
+        // samples) whose values are never used.
+        [[maybe_unused]] size_t tap_set = 0;
+        if constexpr (EQ && DEMAP) tap_set = p.sym_per_set ? static_cast<size_t>(sym / p.sym_per_set) : 0;
+        if constexpr (PREFETCH_TAPS) {
+            if (tap_set != held_set) {
+                held_set = tap_set;
+                constexpr int GO_ = O::kGroupOut;
+                const float2* dummy = p.rx + static_cast<size_t>(sym) * in_stride;      // >= N readable float2
+                const float2* eq_src = p.eq ? p.eq + tap_set * N : dummy;
+                const float* wgt_src = p.wgt ? p.wgt + tap_set * N : reinterpret_cast<const float*>(dummy);
+                static_for<E / GO_>([&](auto Hh) {
+                    constexpr int h = Hh;
+                    const int k = O::reg_pos(LAST, h * GO_) | pos_last;
+                    if constexpr (GO_ == 2) {
+                        const float4 v = *reinterpret_cast<const float4*>(eq_src + k);
+                        eqv[h * 2] = make_float2(v.x, v.y);
+                        eqv[h * 2 + 1] = make_float2(v.z, v.w);
+                        const float2 u = *reinterpret_cast<const float2*>(wgt_src + k);
+                        wv[h * 2] = u.x;
+                        wv[h * 2 + 1] = u.y;
+                    } else {
+                        static_for<GO_>([&](auto G) { constexpr int g = G; eqv[h * GO_ + g] = eq_src[k + g]; wv[h * GO_ + g] = wgt_src[k + g]; });
+                    }
+                });
+            }
+        }
+
         // Reference bits of the symbol (counting only): requested ahead of the samples, parked
-        // in LDS before the transform.  Unconditional for the same reason as the taps below; a
+        // in LDS before the transform.  Unconditional (see the taps above); a
         // missing array is replaced by the symbol's own samples, never looked at.
         constexpr int REF_WORDS = REF_SYM_BYTES / 4;
         constexpr int REF_PER_THREAD = (REF_WORDS + TPS - 1) / TPS;
@@ -492,38 +531,6 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) SDR_WAVES_ATTR rx_fused_k
 #else
         load_symbol(grp, x);
 #endif
-        // Taps and weights of this thread's output bins are requested here, right behind the
-        // samples, and arrive during the transform.  The requests are unconditional: a load under
-        // a run-time branch makes the compiler's wait-count bookkeeping fall back to "wait for
-        // everything" at the next join, which would put the whole latency in front of the
-        // transform.  A missing array is replaced by an always-valid dummy source (this symbol's
-        // own samples) whose values are never used.
-        [[maybe_unused]] float2 eqv[EQ ? E : 1];
-        [[maybe_unused]] float wv[EQ ? E : 1];
-        constexpr bool PREFETCH_TAPS = EQ && DEMAP;
-        [[maybe_unused]] size_t tap_set = 0;
-        if constexpr (EQ && DEMAP) tap_set = p.sym_per_set ? static_cast<size_t>(sym / p.sym_per_set) : 0;
-        if constexpr (PREFETCH_TAPS) {
-            constexpr int GO_ = O::kGroupOut;
-            const float2* dummy = p.rx + static_cast<size_t>(sym) * in_stride;      // >= N readable float2
-            const float2* eq_src = p.eq ? p.eq + tap_set * N : dummy;
-            const float* wgt_src = p.wgt ? p.wgt + tap_set * N : reinterpret_cast<const float*>(dummy);
-            static_for<E / GO_>([&](auto Hh) {
-                constexpr int h = Hh;
-                const int k = O::reg_pos(LAST, h * GO_) | pos_last;
-                if constexpr (GO_ == 2) {
-                    const float4 v = *reinterpret_cast<const float4*>(eq_src + k);
-                    eqv[h * 2] = make_float2(v.x, v.y);
-                    eqv[h * 2 + 1] = make_float2(v.z, v.w);
-                    const float2 u = *reinterpret_cast<const float2*>(wgt_src + k);
-                    wv[h * 2] = u.x;
-                    wv[h * 2 + 1] = u.y;
-                } else {
-                    static_for<GO_>([&](auto G) { constexpr int g = G; eqv[h * GO_ + g] = eq_src[k + g]; wv[h * GO_ + g] = wgt_src[k + g]; });
-                }
-            });
-        }
-
         if constexpr (FULL && DEMAP) {
             static_for<REF_PER_THREAD>([&](auto R) {
                 constexpr int r = R;
@@ -713,7 +720,9 @@ int launch_rx_fused(sdr_ctx* ctx, const RxParams& p)
     // Each workgroup takes a run of consecutive symbol groups.  Short runs (many workgroups, the
     // hardware dispatcher balancing them) measured faster than a resident grid striding over the
     // batch; the per-workgroup twiddle set-up is amortised over the run.
-    unsigned long long per_wg = p.counters ? 8 : 2;              // counting ends every workgroup with atomics: longer runs
+    // counting ends every workgroup with atomics: longer runs.  (Longer runs for the tap-holding
+    // variants measured slower: what they save in tap loads they lose in load balance.)
+    unsigned long long per_wg = p.counters ? 8 : 2;
     if (tune.groups_per_wg >= 0) per_wg = static_cast<unsigned long long>(tune.groups_per_wg);
     if (per_wg == 0 || tune.debug) {
         int nb = 0;
