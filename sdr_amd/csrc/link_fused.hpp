@@ -13,6 +13,8 @@
 #pragma once
 
 #include "rng.hpp"
+#include <type_traits>
+
 #include "rx_fused.hpp"
 
 namespace sdr {
@@ -112,10 +114,11 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) tx_fused_kernel(const TxP
     constexpr int SYM_BYTES = O::max_sym_bytes();
     constexpr int DATA_BYTES = SYM_BYTES * SPW;
     constexpr int TW_BYTES = O::kMidCount * 8;
-    constexpr int IDX_BYTES = SRC_GLOBAL ? 0 : N * SPW;
+    using idx_t = std::conditional_t<(MI + MQ > 8), uint16_t, uint8_t>;
+    constexpr int IDX_BYTES = SRC_GLOBAL ? 0 : N * SPW * static_cast<int>(sizeof(idx_t));
     constexpr int TIME_OFF = (DATA_BYTES + TW_BYTES + IDX_BYTES + 15) & ~15;
     __shared__ __attribute__((aligned(16))) unsigned char lds[TIME_OFF + N * 8 * SPW + 16];
-    unsigned char* lds_idx = lds + DATA_BYTES + TW_BYTES;
+    idx_t* lds_idx = reinterpret_cast<idx_t*>(lds + DATA_BYTES + TW_BYTES);
     float2* lds_time = reinterpret_cast<float2*>(lds + TIME_OFF) + slot_of(threadIdx.x, TPS) * N;   // this symbol's time-domain samples
 
     const int tid = threadIdx.x;
@@ -172,7 +175,7 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) tx_fused_kernel(const TxP
                     xr = tr; xi = ti;
                 }
                 x[m] = make_float2(xr, xi);
-                if (p.tx_bits) lds_idx[slot * N + i] = static_cast<unsigned char>(idx);
+                if (p.tx_bits) lds_idx[slot * N + i] = static_cast<idx_t>(idx);
             });
         }
 

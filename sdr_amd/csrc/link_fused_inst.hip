@@ -24,6 +24,7 @@ int SDR_CAT(tx_fused_dispatch_, SDR_LOG2N)(sdr_ctx* ctx, const TxParams& p, int 
         case 4: return launch_tx_fused<L, 2, 2, false, true>(ctx, p);
         case 6: return launch_tx_fused<L, 3, 3, false, true>(ctx, p);
         case 8: return launch_tx_fused<L, 4, 4, false, true>(ctx, p);
+        case 10: return launch_tx_fused<L, 5, 5, false, true>(ctx, p);
         default: return fail(SDR_ERR_UNSUPPORTED, "modulation %d has no fused generator", mod);
     }
 }
@@ -37,6 +38,7 @@ int SDR_CAT(mc_fused_dispatch_, SDR_LOG2N)(sdr_ctx* ctx, const McParams& p, int 
         case 4: return launch_mc_fused<L, 2, 2>(ctx, p);
         case 6: return launch_mc_fused<L, 3, 3>(ctx, p);
         case 8: return launch_mc_fused<L, 4, 4>(ctx, p);
+        case 10: return launch_mc_fused<L, 5, 5>(ctx, p);
         default: return fail(SDR_ERR_UNSUPPORTED, "modulation %d has no fused Monte-Carlo kernel", mod);
     }
 }

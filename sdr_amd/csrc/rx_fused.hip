@@ -41,7 +41,7 @@ int dispatch(sdr_ctx* ctx, unsigned log2n, const RxParams& p, int mod, int varia
 bool rx_fused_supported(uint32_t n_fft, uint32_t mod)
 {
     if (!is_pow2(n_fft) || n_fft < 64 || n_fft > 4096) return false;
-    return mod == 0 || mod == 1 || mod == 2 || mod == 4 || mod == 6 || mod == 8;
+    return mod == 0 || mod == 1 || mod == 2 || mod == 4 || mod == 6 || mod == 8 || mod == 10;
 }
 
 // The vector accesses of the kernel need 16-byte aligned buffers and an even CP; anything else

@@ -27,6 +27,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include <utility>
 
 #include "fft_plans.hpp"
@@ -328,11 +329,11 @@ __device__ __forceinline__ void stream_store2(float* dst, float a, float b)
 }
 
 // LLR staging through LDS: per-lane chunk of C floats -> lane-contiguous vectors (coalesced stores)
-constexpr int stage_stride_bytes(int c) { return c == 6 ? 24 : c == 8 ? 48 : c == 12 ? 48 : c == 16 ? 80 : c * 4; }
+constexpr int stage_stride_bytes(int c) { return c == 6 ? 24 : c == 8 ? 48 : c == 12 ? 48 : c == 16 ? 80 : c == 20 ? 80 : c * 4; }
 #ifdef SDR_NO_STAGE8
 constexpr bool stage_wanted(int c) { return c == 6 || c == 12 || c == 16; }
 #else
-constexpr bool stage_wanted(int c) { return c == 6 || c == 8 || c == 12 || c == 16; }
+constexpr bool stage_wanted(int c) { return c == 6 || c == 8 || c == 12 || c == 16 || c == 20; }
 #endif
 
 __device__ __forceinline__ unsigned ref_bits(const uint8_t* __restrict__ s, size_t pos, int nbits)
@@ -376,7 +377,8 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) SDR_WAVES_ATTR rx_fused_k
     constexpr int SYM_BYTES = O::max_sym_bytes();
     constexpr int DATA_BYTES = SYM_BYTES * SPW;
     constexpr int TW_BYTES = O::kMidCount * 8;
-    constexpr int IDX_BYTES = (FULL && DEMAP) ? N * SPW : 0;
+    using idx_t = std::conditional_t<(BPS > 8), uint16_t, uint8_t>;      // one hard decision
+    constexpr int IDX_BYTES = (FULL && DEMAP) ? N * SPW * static_cast<int>(sizeof(idx_t)) : 0;
     constexpr int REF_SYM_BYTES = N * (DEMAP ? BPS : 8) / 8;      // reference bits of one symbol
     constexpr int REF_BYTES = (FULL && DEMAP) ? REF_SYM_BYTES * SPW : 0;
     constexpr int CHUNK = O::kGroupOut * BPS;                      // LLR floats per lane per output block
@@ -397,7 +399,7 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) SDR_WAVES_ATTR rx_fused_k
     constexpr int LDS_BYTES = STG_ALIAS ? DATA_BYTES + TW_BYTES + IDX_BYTES + REF_BYTES : STG_OFF + STG_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES + 16];
     unsigned char* lds_data = lds;
-    unsigned char* lds_idx = lds + DATA_BYTES + TW_BYTES;
+    [[maybe_unused]] idx_t* lds_idx = reinterpret_cast<idx_t*>(lds + DATA_BYTES + TW_BYTES);
     [[maybe_unused]] unsigned char* lds_ref = lds + DATA_BYTES + TW_BYTES + IDX_BYTES;
 
     const int tid = threadIdx.x;
@@ -612,16 +614,21 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) SDR_WAVES_ATTR rx_fused_k
                     if (p.llr && active) store_floats<GO * BPS>(p.llr + (bin0 + k) * BPS, l);
                 }
                 if constexpr (FULL) {
-                    if (p.hard) static_for<GO>([&](auto G) { constexpr int g = G; lds_idx[slot * N + k + g] = static_cast<unsigned char>(idx[g]); });
+                    if (p.hard) static_for<GO>([&](auto G) { constexpr int g = G; lds_idx[slot * N + k + g] = static_cast<idx_t>(idx[g]); });
                     if (p.counters && active) {
-                        // GO adjacent points: GO * BPS <= 16 reference bits, inside two bytes
-                        static_assert(GO * BPS <= 16, "reference bits of one register group fit two bytes");
+                        // GO adjacent points: GO * BPS <= 20 reference bits starting at a multiple of
+                        // GO * BPS bits, i.e. inside a four-byte window that starts at the bit's byte
+                        static_assert(GO * BPS <= 25, "reference bits of one register group fit a four-byte window");
                         const unsigned bit = static_cast<unsigned>(k) * BPS;
                         const unsigned b0 = bit >> 3;
-                        const unsigned b1 = (b0 + 1 < REF_SYM_BYTES) ? b0 + 1 : b0;
                         const unsigned char* rs = lds_ref + slot * REF_SYM_BYTES;
-                        const unsigned two = (static_cast<unsigned>(rs[b0]) << 8) | rs[b1];
-                        const unsigned both = (two >> (16u - (bit & 7u) - GO * BPS)) & ((1u << (GO * BPS)) - 1u);
+                        unsigned window = 0;
+                        static_for<(GO * BPS + 7 + 7) / 8>([&](auto I) {
+                            constexpr unsigned i = I;
+                            const unsigned bi = (b0 + i < REF_SYM_BYTES) ? b0 + i : REF_SYM_BYTES - 1;
+                            window |= static_cast<unsigned>(rs[bi]) << (24u - 8u * i);
+                        });
+                        const unsigned both = (window >> (32u - (bit & 7u) - GO * BPS)) & ((1u << (GO * BPS)) - 1u);
                         unsigned n_bit = 0, n_sym_err = 0, n_sign = 0, n_abs = 0;      // <= 16 LLRs: no overflow
                         unsigned long long wide_abs = 0;
                         static_for<GO>([&](auto G) {

@@ -33,6 +33,7 @@ int SDR_CAT(rx_fused_dispatch_, SDR_LOG2N)(sdr_ctx* ctx, const RxParams& p, int 
         case 4: SDR_RX_CASE(2, 2)
         case 6: SDR_RX_CASE(3, 3)
         case 8: SDR_RX_CASE(4, 4)
+        case 10: SDR_RX_CASE(5, 5)
         default: return fail(SDR_ERR_UNSUPPORTED, "modulation %d has no fused kernel", mod);
     }
 #undef SDR_RX_CASE

@@ -189,7 +189,7 @@ def test_zf_taps(ctx, oracle):
 
 # ---- fused receive path ------------------------------------------------------------------------
 CASES = [(64, 16, 2), (64, 16, 4), (128, 32, 6), (256, 64, 8), (512, 128, 4), (1024, 256, 4), (1024, 256, 6),
-         (2048, 512, 6), (4096, 1024, 8), (1024, 256, 2), (4096, 1024, 2), (2048, 0, 8), (32, 8, 4), (1024, 100, 1), (256, 64, 10)]
+         (2048, 512, 6), (4096, 1024, 8), (1024, 256, 2), (4096, 1024, 2), (2048, 0, 8), (32, 8, 4), (1024, 100, 1), (256, 64, 10), (1024, 256, 10), (4096, 1024, 10), (64, 16, 10)]
 
 
 @pytest.mark.parametrize("n,cp,bps", CASES)
