@@ -27,7 +27,7 @@ int ofdm_rx_device(sdr_ctx* ctx, bool is_double, const void* d_in, size_t n_fft,
     if (n_sym == 0 || n_fft == 0) return SDR_OK;
     if (!is_pow2(n_fft)) return fail(SDR_ERR_NOT_POW2, "%s", kPow2Message);
     if (!d_in || !d_out) return fail(SDR_ERR_INVALID, "null device pointer");
-    if (!is_double && n_fft <= 4096 && cp <= 0xFFFFFFFFu && cp % 2 == 0 && rx_fused_supported(static_cast<uint32_t>(n_fft), 0) &&
+    if (!is_double && n_fft <= 8192 && cp <= 0xFFFFFFFFu && cp % 2 == 0 && rx_fused_supported(static_cast<uint32_t>(n_fft), 0) &&
         reinterpret_cast<uintptr_t>(d_in) % 16 == 0 && reinterpret_cast<uintptr_t>(d_out) % 16 == 0)
         return rx_fft_only_launch(ctx, d_in, static_cast<uint32_t>(n_fft), static_cast<uint32_t>(cp), n_sym, d_out);
     return is_double ? fft_generic_f64(ctx, d_in, d_out, n_fft, false, n_fft + cp, cp, n_fft, 0, 0, n_sym)

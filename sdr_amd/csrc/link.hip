@@ -19,7 +19,7 @@ namespace sdr {
 #define SDR_DECL_LINK(L) \
     int tx_fused_dispatch_##L(sdr_ctx*, const TxParams&, int); \
     int mc_fused_dispatch_##L(sdr_ctx*, const McParams&, int);
-SDR_DECL_LINK(6) SDR_DECL_LINK(7) SDR_DECL_LINK(8) SDR_DECL_LINK(9) SDR_DECL_LINK(10) SDR_DECL_LINK(11) SDR_DECL_LINK(12)
+SDR_DECL_LINK(6) SDR_DECL_LINK(7) SDR_DECL_LINK(8) SDR_DECL_LINK(9) SDR_DECL_LINK(10) SDR_DECL_LINK(11) SDR_DECL_LINK(12) SDR_DECL_LINK(13)
 #undef SDR_DECL_LINK
 
 namespace {
@@ -34,6 +34,7 @@ int tx_dispatch(sdr_ctx* ctx, unsigned log2n, const TxParams& p, int mod)
         case 10: return tx_fused_dispatch_10(ctx, p, mod);
         case 11: return tx_fused_dispatch_11(ctx, p, mod);
         case 12: return tx_fused_dispatch_12(ctx, p, mod);
+        case 13: return tx_fused_dispatch_13(ctx, p, mod);
         default: return fail(SDR_ERR_UNSUPPORTED, "n_fft = 2^%u has no fused kernel", log2n);
     }
 }
@@ -47,6 +48,7 @@ int mc_dispatch(sdr_ctx* ctx, unsigned log2n, const McParams& p, int mod)
         case 10: return mc_fused_dispatch_10(ctx, p, mod);
         case 11: return mc_fused_dispatch_11(ctx, p, mod);
         case 12: return mc_fused_dispatch_12(ctx, p, mod);
+        case 13: return mc_fused_dispatch_13(ctx, p, mod);
         default: return fail(SDR_ERR_UNSUPPORTED, "n_fft = 2^%u has no fused kernel", log2n);
     }
 }
@@ -186,7 +188,7 @@ int link_generate(sdr_ctx* ctx, const sdr_link_args& a)
 // Batched ofdm::tx for the tuned sizes (bins in device memory -> samples with cyclic prefix).
 bool tx_fused_ok(size_t n_fft, size_t cp, const void* d_in, const void* d_out)
 {
-    return n_fft <= 4096 && rx_fused_supported(static_cast<uint32_t>(n_fft), 0) && cp <= n_fft && is_aligned(d_in, 16) && is_aligned(d_out, 8);
+    return n_fft <= 8192 && rx_fused_supported(static_cast<uint32_t>(n_fft), 0) && cp <= n_fft && is_aligned(d_in, 16) && is_aligned(d_out, 8);
 }
 int tx_fused_launch(sdr_ctx* ctx, const void* d_in, uint32_t n_fft, uint32_t cp, uint64_t n_sym, void* d_out)
 {

@@ -1,4 +1,4 @@
-// link_fused.hpp -- tuned transmit-side and Monte-Carlo kernels for n_fft = 64..4096 (fp32).
+// link_fused.hpp -- tuned transmit-side and Monte-Carlo kernels for n_fft = 64..8192 (fp32).
 //
 //   tx_fused_kernel   ofdm::tx for a batch (lib/inc/ofdm.hpp:13-24: IFFT with the reference
 //                     network, /N, cyclic prefix), optionally fed by the Philox index generator +

@@ -16,6 +16,7 @@ int rx_fused_dispatch_9(sdr_ctx*, const RxParams&, int, int);
 int rx_fused_dispatch_10(sdr_ctx*, const RxParams&, int, int);
 int rx_fused_dispatch_11(sdr_ctx*, const RxParams&, int, int);
 int rx_fused_dispatch_12(sdr_ctx*, const RxParams&, int, int);
+int rx_fused_dispatch_13(sdr_ctx*, const RxParams&, int, int);
 
 namespace {
 
@@ -31,6 +32,7 @@ int dispatch(sdr_ctx* ctx, unsigned log2n, const RxParams& p, int mod, int varia
         case 10: return rx_fused_dispatch_10(ctx, p, mod, variant);
         case 11: return rx_fused_dispatch_11(ctx, p, mod, variant);
         case 12: return rx_fused_dispatch_12(ctx, p, mod, variant);
+        case 13: return rx_fused_dispatch_13(ctx, p, mod, variant);
         default: return fail(SDR_ERR_UNSUPPORTED, "n_fft = 2^%u has no fused kernel", log2n);
     }
 }
@@ -40,7 +42,7 @@ int dispatch(sdr_ctx* ctx, unsigned log2n, const RxParams& p, int mod, int varia
 // mod = 0 asks about the FFT-only form.
 bool rx_fused_supported(uint32_t n_fft, uint32_t mod)
 {
-    if (!is_pow2(n_fft) || n_fft < 64 || n_fft > 4096) return false;
+    if (!is_pow2(n_fft) || n_fft < 64 || n_fft > 8192) return false;
     return mod == 0 || mod == 1 || mod == 2 || mod == 4 || mod == 6 || mod == 8 || mod == 10;
 }
 

@@ -1,4 +1,4 @@
-// rx_fused.hpp -- the tuned fused receive kernel (fp32, n_fft = 64..4096):
+// rx_fused.hpp -- the tuned fused receive kernel (fp32, n_fft = 64..8192):
 //   CP removal -> FFT (reference radix-2 DIT network) -> one-tap equalise -> max-log LLR
 //   (+ optional nearest() hard bits, FFT bins, BER/LLR counters).
 //
@@ -360,7 +360,7 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 #ifndef SDR_EQ_WPE
 #define SDR_EQ_WPE 2
 #endif
-#define SDR_WAVES_ATTR __attribute__((amdgpu_waves_per_eu((EQ || FULL) ? SDR_EQ_WPE : 1)))
+#define SDR_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(((EQ || FULL) && LOG2N <= 12) ? SDR_EQ_WPE : 1)))   // N = 8192: LDS allows one workgroup per CU anyway
 #endif
 
 // MI + MQ == 0: FFT only (bins to p.fft).  FULL: every output optional at run time.

@@ -189,7 +189,7 @@ def test_zf_taps(ctx, oracle):
 
 # ---- fused receive path ------------------------------------------------------------------------
 CASES = [(64, 16, 2), (64, 16, 4), (128, 32, 6), (256, 64, 8), (512, 128, 4), (1024, 256, 4), (1024, 256, 6),
-         (2048, 512, 6), (4096, 1024, 8), (1024, 256, 2), (4096, 1024, 2), (2048, 0, 8), (32, 8, 4), (1024, 100, 1), (256, 64, 10), (1024, 256, 10), (4096, 1024, 10), (64, 16, 10)]
+         (2048, 512, 6), (4096, 1024, 8), (1024, 256, 2), (4096, 1024, 2), (2048, 0, 8), (32, 8, 4), (1024, 100, 1), (256, 64, 10), (1024, 256, 10), (4096, 1024, 10), (64, 16, 10), (8192, 2048, 4), (8192, 2048, 6), (8192, 0, 10)]
 
 
 @pytest.mark.parametrize("n,cp,bps", CASES)
@@ -226,7 +226,7 @@ def test_demod_parity(ctx, oracle, n, cp, bps):
     assert same(counters.cpu().numpy(), 2 * c)
 
 
-@pytest.mark.parametrize("n,cp,bps", [(64, 16, 2), (1024, 256, 4), (2048, 512, 6), (4096, 1024, 8)])
+@pytest.mark.parametrize("n,cp,bps", [(64, 16, 2), (1024, 256, 4), (2048, 512, 6), (4096, 1024, 8), (8192, 2048, 6)])
 def test_demod_with_equaliser_sets(ctx, oracle, n, cp, bps):
     from sdr_amd.link import noise_sigma
     rng = np.random.default_rng(n)
