@@ -360,7 +360,10 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 #ifndef SDR_EQ_WPE
 #define SDR_EQ_WPE 2
 #endif
-#define SDR_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(((EQ || FULL) && LOG2N <= 12) ? SDR_EQ_WPE : 1)))   // N = 8192: LDS allows one workgroup per CU anyway
+// N = 8192 (E = 32): FULL variants are held to one workgroup per CU by LDS and the tap-holding ones
+// would spill (measured 49 -> 33 %); the others fit two if
+// they stay within 256 registers.
+#define SDR_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(LOG2N >= 13 ? ((FULL || EQ) ? 1 : 2) : ((EQ || FULL) ? SDR_EQ_WPE : 1))))
 #endif
 
 // MI + MQ == 0: FFT only (bins to p.fft).  FULL: every output optional at run time.
@@ -393,7 +396,9 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) SDR_WAVES_ATTR rx_fused_k
 #ifdef SDR_NO_STG_ALIAS
     constexpr bool STG_ALIAS = false;
 #else
-    constexpr bool STG_ALIAS = STAGE && STG_BYTES <= DATA_BYTES && O::kWG == 64;   // multi-wave: the barrier it needs costs more (measured)
+    // multi-wave workgroups need a barrier for it, which costs more than it gains at N = 2048/4096
+    // (measured); at N = 8192 it is the difference between one and two workgroups per CU
+    constexpr bool STG_ALIAS = STAGE && STG_BYTES <= DATA_BYTES && (O::kWG == 64 || LOG2N >= 13);
 #endif
     constexpr int STG_OFF = STG_ALIAS ? 0 : (DATA_BYTES + TW_BYTES + IDX_BYTES + REF_BYTES + 15) & ~15;
     constexpr int LDS_BYTES = STG_ALIAS ? DATA_BYTES + TW_BYTES + IDX_BYTES + REF_BYTES : STG_OFF + STG_BYTES;
@@ -543,6 +548,8 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) SDR_WAVES_ATTR rx_fused_k
         }
 
         fft_run<LOG2N>(x, lds_data, addr, tw);
+
+        if constexpr (STG_ALIAS && O::kWG > 64) __syncthreads();   // every wave is past its last exchange read
 
         // ---- epilogue: bins are in natural order, k = reg_pos(LAST, m) | pos_last ----
         constexpr int GO = O::kGroupOut;   // adjacent bins held in registers m = GO*h + (0..GO-1)
