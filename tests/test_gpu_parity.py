@@ -480,3 +480,42 @@ def test_c_abi_argument_errors(ctx):
     assert lib.sdr_ofdm_demod_c32(h, ctypes.byref(args(d_counters=cnt.data_ptr()))) == capi.SDR_ERR_INVALID   # counters without reference bits
     assert lib.sdr_ofdm_demod_c32(h, ctypes.byref(args(n_sym=0))) == capi.SDR_OK                                # empty batch: nothing to do
     torch.cuda.synchronize()
+
+
+def test_two_contexts_in_two_threads(oracle):
+    """Contexts are independent (include/sdr_amd.h): two host threads, each with a context and a
+    stream of its own, run the counting receive path concurrently and both match the oracle."""
+    import threading
+    from sdr_amd.ops import Context
+    from sdr_amd.link import noise_sigma
+    n, cp, bps, n_sym = 1024, 256, 4, 64
+    rx, bits = oracle.link_generate(n, cp, bps, 21, 0, n_sym, np.float32(noise_sigma(n, bps, 8.0)))
+    ref = oracle.demod(rx, n, cp, bps, weight=1.0, want_fft=False)
+    want_errors = oracle.count_bit_errors(ref["hard"], bits)
+    results, failures = {}, []
+
+    def worker(tag):
+        try:
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                c = Context(0)
+                drx, dbits = dev(rx), dev(bits)
+                cnt = torch.zeros(8, dtype=torch.int64, device="cuda")
+                for _ in range(20):
+                    out = c.demod(drx, n, cp, bps, llr_weight=1.0, want_hard=True, ref_hard=dbits, counters=cnt)
+                stream.synchronize()
+                results[tag] = (out.llr.cpu().numpy(), out.hard.cpu().numpy(), cnt.cpu().numpy())
+                c.close()
+        except Exception as e:      # surfaced below: an assertion in a thread would be lost
+            failures.append((tag, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not failures, failures
+    for tag in range(2):
+        llr, hard, cnt = results[tag]
+        assert same(llr, ref["llr"]) and same(hard, ref["hard"])
+        assert cnt[0] == 20 * want_errors and cnt[4] == 20 * n_sym
