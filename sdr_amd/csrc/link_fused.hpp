@@ -104,7 +104,8 @@ __device__ __forceinline__ void for_each_tx_index(unsigned long long seed, unsig
 
 // MI + MQ == 0 with SRC_GLOBAL: plain batched ofdm::tx.  SRC_GLOBAL = false: Philox generator.
 template <int LOG2N, int MI, int MQ, bool SRC_GLOBAL, bool NOISE>
-__global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) tx_fused_kernel(const TxParams p)
+// two waves per SIMD where LDS allows two workgroups: left alone the compiler takes 256 + a few registers
+__global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) __attribute__((amdgpu_waves_per_eu(LOG2N <= 12 ? 2 : 1))) tx_fused_kernel(const TxParams p)
 {
     using O = PlanOps<LOG2N>;
     using P = typename O::P;
