@@ -131,6 +131,18 @@ def time_workload(ctx, torch, dist, name, steps, warmup, world, rank, n_sym_over
         t = torch.tensor([elapsed], dtype=torch.float64, device=("cuda" if dist.get_backend() == "nccl" else "cpu"))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # the memory system's rate for this traffic shape: same bytes, same access pattern, no arithmetic
+    copy_gbs = None
+    if eq is None:
+        for _ in range(2):
+            ctx.copy_shape(rx, n_fft, cp, bps, llr)
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        for _ in range(max(3, steps // 2)):
+            ctx.copy_shape(rx, n_fft, cp, bps, llr)
+        c1.record()
+        torch.cuda.synchronize()
+        copy_gbs = algorithmic_bytes_per_symbol(n_fft, bps) * n_sym / (c0.elapsed_time(c1) / max(3, steps // 2) / 1e3) / 1e9
     launch_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
     avg_launch_s = sum(launch_ms) / len(launch_ms) / 1e3
     b_sym = algorithmic_bytes_per_symbol(n_fft, bps)
@@ -138,6 +150,7 @@ def time_workload(ctx, torch, dist, name, steps, warmup, world, rank, n_sym_over
     res = {
         "n_fft": n_fft, "cp": cp, "bps": bps, "n_sym": n_sym, "elapsed": elapsed,
         "sym_per_s": world * n_sym * steps / elapsed,
+        "copy_shape_gbs": copy_gbs,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": measured_traffic(name, n_sym), "traffic_unit": "bytes per launch (rocprofv3 PMC, separate passes; profiles/r1_traffic.json)",
                      "algorithmic_bytes_per_launch": b_sym * n_sym, "bytes_per_symbol": b_sym, "symbols_per_launch": n_sym, "avg_launch_ms": avg_launch_s * 1e3},
@@ -190,6 +203,9 @@ def main():
         r = time_workload(ctx, torch, dist, "fft1024_64qam_1M", max(3, args.steps // 2), 2, 1, 0)
         extra["fft1024_64qam_1M"] = {"sym_per_s": r["sym_per_s"], "llr_gbit_per_s": r["sym_per_s"] * r["n_fft"] * r["bps"] / 1e9,
                                      "hbm_frac": r["roofline"]["frac"], "achieved_GBs": r["roofline"]["achieved"]}
+    if main_res.get("copy_shape_gbs"):
+        extra["copy_of_same_shape"] = {"achieved_GBs": main_res["copy_shape_gbs"], "kernel_over_copy": main_res["roofline"]["achieved"] / main_res["copy_shape_gbs"],
+                                       "what": "sdr_diag_copy_shape_c32: the kernel's bytes and access pattern with no arithmetic, same buffers"}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
         cpu = cpu_baseline(main_res["n_fft"], main_res["cp"], main_res["bps"])

@@ -151,6 +151,12 @@ int sdr_ofdm_demod_c32(sdr_ctx* ctx, const sdr_demod_args* args);
  * n_sets = number of tap / weight sets behind d_eq / d_llr_weight (ignored when both are NULL). */
 int sdr_ofdm_demod_host_c32(sdr_ctx* ctx, const sdr_demod_args* host_args, size_t n_sets);
 
+/* Diagnostic (no reference counterpart, no arithmetic): moves exactly the bytes of
+ * sdr_ofdm_demod_c32 with LLR output only -- reads the n_sym*n_fft payload samples, writes
+ * n_sym*n_fft*mod floats (values unspecified) -- with the same access pattern, so that a
+ * benchmark can quote the receive kernel against the memory system's rate for its shape. */
+int sdr_diag_copy_shape_c32(sdr_ctx* ctx, const void* d_rx, uint32_t n_fft, uint32_t cp, uint32_t mod, uint64_t n_sym, float* d_llr);
+
 /* Equaliser taps and LLR weights from a channel estimate H (n values):
  *   p = |H|^2, G = conj(H)/p, w = norm^2 * p * inv_n0. */
 int sdr_zf_taps_c32(sdr_ctx* ctx, int mod, const void* d_chan, size_t n, float inv_n0, void* d_taps, float* d_weight);

@@ -214,6 +214,12 @@ int sdr_ofdm_demod_c32(sdr_ctx* ctx, const sdr_demod_args* args)
     return demap_after_fft(ctx, a, d_fft);
 }
 
+int sdr_diag_copy_shape_c32(sdr_ctx* ctx, const void* d_rx, uint32_t n_fft, uint32_t cp, uint32_t mod, uint64_t n_sym, float* d_llr)
+{
+    SDR_TRY(ensure_device(ctx));
+    return copy_shape_launch(ctx, d_rx, n_fft, cp, mod, n_sym, d_llr);
+}
+
 int sdr_zf_taps_c32(sdr_ctx* ctx, int mod, const void* d_chan, size_t n, float inv_n0, void* d_taps, float* d_weight)
 {
     SDR_TRY(ensure_device(ctx));

@@ -25,6 +25,7 @@ bool rx_fused_supported(uint32_t n_fft, uint32_t mod);
 bool rx_fused_layout_ok(const sdr_demod_args& a);
 int rx_fused_launch(sdr_ctx* ctx, const sdr_demod_args& a);
 int rx_fft_only_launch(sdr_ctx* ctx, const void* d_in, uint32_t n_fft, uint32_t cp, uint64_t n_sym, void* d_out);
+int copy_shape_launch(sdr_ctx* ctx, const void* d_rx, uint32_t n_fft, uint32_t cp, uint32_t bps, uint64_t n_sym, float* d_out);
 
 // link.hip: frame generator, AWGN, Monte-Carlo link.
 int link_generate(sdr_ctx* ctx, const sdr_link_args& a);

@@ -95,4 +95,58 @@ int rx_fft_only_launch(sdr_ctx* ctx, const void* d_in, uint32_t n_fft, uint32_t 
     return dispatch(ctx, ilog2(n_fft), p, 0, 2);
 }
 
+// ---- diagnostic: the memory system's ceiling for this kernel's traffic shape -------------------
+// Same access pattern as the fused receive kernel and no arithmetic: one wave per symbol reads
+// the symbol's n_fft samples (cyclic prefix skipped) with 16-byte loads, then writes the symbol's
+// n_fft * bps floats with lane-contiguous 16-byte non-temporal stores; two consecutive symbols
+// per workgroup; the same XCD-aware workgroup order.  bench.py reports its rate beside the
+// kernel's, so that "fraction of the HBM peak" can be read against what a pure copy of this
+// shape reaches on the same box.
+namespace {
+
+__global__ void __launch_bounds__(64) copy_shape_kernel(const float4* __restrict__ rx, float* __restrict__ out, unsigned n_fft, unsigned cp,
+                                                        unsigned bps, unsigned long long n_sym, unsigned xcd_window)
+{
+    unsigned long long wg = blockIdx.x;
+    if (xcd_window >= 8) {
+        const unsigned long long win = xcd_window;
+        const unsigned long long full = (static_cast<unsigned long long>(gridDim.x) / win) * win;
+        if (wg < full) {
+            const unsigned long long r = wg % win;
+            wg = wg - r + (r & 7) * (win >> 3) + (r >> 3);
+        }
+    }
+    const unsigned lane = threadIdx.x;
+    const unsigned in_vec = n_fft / 2;                    // float4 = two samples
+    const unsigned out_vec = n_fft * bps / 4;             // float4 = four LLRs
+    for (unsigned long long sym = wg * 2; sym < wg * 2 + 2 && sym < n_sym; ++sym) {
+        const float4* src = rx + (sym * (static_cast<unsigned long long>(n_fft) + cp) + cp) / 2;
+        float acc = 0.0f;
+        for (unsigned i = lane; i < in_vec; i += 64) {
+            const float4 v = src[i];
+            acc += v.x + v.y + v.z + v.w;
+        }
+        float* dst = out + sym * static_cast<unsigned long long>(n_fft) * bps;
+        for (unsigned i = lane; i < out_vec; i += 64) stream_store4(dst + 4ull * i, acc, acc, acc, acc);
+    }
+}
+
+} // namespace
+
+int copy_shape_launch(sdr_ctx* ctx, const void* d_rx, uint32_t n_fft, uint32_t cp, uint32_t bps, uint64_t n_sym, float* d_out)
+{
+    if (n_fft < 64 || (n_fft & (n_fft - 1)) != 0 || cp % 2 != 0 || bps == 0 || (static_cast<uint64_t>(n_fft) * bps) % 4 != 0)
+        return fail(SDR_ERR_INVALID, "copy-shape diagnostic: n_fft >= 64 power of two, even cp");
+    if (!aligned(d_rx, 16) || !aligned(d_out, 16) || !d_rx || !d_out) return fail(SDR_ERR_INVALID, "copy-shape diagnostic: 16-byte aligned buffers");
+    const unsigned long long blocks = (n_sym + 1) / 2;
+    if (blocks == 0) return SDR_OK;
+    if (blocks > 0x7FFFFFFFull) return fail(SDR_ERR_UNSUPPORTED, "batch too large for one launch");
+    const RxTuning& tune = rx_tuning();
+    hipLaunchKernelGGL(copy_shape_kernel, dim3(static_cast<unsigned>(blocks)), dim3(64), 0, ctx->stream, static_cast<const float4*>(d_rx), d_out,
+                       n_fft, cp, bps, static_cast<unsigned long long>(n_sym), static_cast<unsigned>(tune.xcd_window > 0 ? tune.xcd_window : 0));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, "copy_shape_kernel launch");
+    return SDR_OK;
+}
+
 } // namespace sdr

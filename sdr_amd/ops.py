@@ -202,6 +202,14 @@ class Context:
         return DemodResult(llr, hard, fft)
 
     # ---- device frame generator / AWGN / Monte-Carlo link ----
+    def copy_shape(self, rx: torch.Tensor, n_fft: int, cp: int, mod, out_llr: torch.Tensor) -> None:
+        """Diagnostic: the bytes of demod(LLR only) with no arithmetic (sdr_diag_copy_shape_c32)."""
+        bps = mod_bits(mod)
+        n_sym = rx.numel() // (n_fft + cp)
+        _need(rx, torch.complex64, "rx", n_sym * (n_fft + cp))
+        _need(out_llr, torch.float32, "llr", n_sym * n_fft * bps)
+        check(self.lib.sdr_diag_copy_shape_c32(self._h, _ptr(rx), n_fft, cp, bps, n_sym, _ptr(out_llr)))
+
     def _link_args(self, n_fft, cp, mod, seed, first_symbol, n_sym, sigma, sym_per_set=0, llr_weight=1.0) -> LinkArgs:
         a = LinkArgs()
         a.struct_size = ctypes.sizeof(LinkArgs)

@@ -519,3 +519,12 @@ def test_two_contexts_in_two_threads(oracle):
         llr, hard, cnt = results[tag]
         assert same(llr, ref["llr"]) and same(hard, ref["hard"])
         assert cnt[0] == 20 * want_errors and cnt[4] == 20 * n_sym
+
+
+def test_copy_shape_diagnostic_touches_every_output(ctx):
+    n, cp, bps, n_sym = 1024, 256, 6, 37
+    rx = torch.ones((n_sym, n + cp), dtype=torch.complex64, device="cuda")
+    out = torch.full((n_sym, n, bps), float("nan"), dtype=torch.float32, device="cuda")
+    ctx.copy_shape(rx, n, cp, bps, out)
+    torch.cuda.synchronize()
+    assert not torch.isnan(out).any()
