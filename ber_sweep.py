@@ -47,8 +47,16 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # SDR_BENCH_BACKEND=gloo: rehearsal on a box with fewer GPUs than ranks (ranks share devices,
+        # the counter all-reduce goes over gloo on host copies); real runs use RCCL.
+        backend = os.environ.get("SDR_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            local_rank = local_rank % torch.cuda.device_count()
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
         local_rank = 0
@@ -72,7 +80,12 @@ def main():
             ctx.link_ber(args.n_fft, args.cp, p.mod_bits, args.seed, g0, count * link.SYMBOLS_PER_FRAME,
                          link.noise_sigma(args.n_fft, p.mod_bits, p.ebn0_db), link.llr_weight(p.mod_bits, p.ebn0_db), counters=counters[i])
         if world > 1:
-            dist.all_reduce(counters, op=dist.ReduceOp.SUM)      # the only collective: O(KiB) of int64 over RCCL
+            if dist.get_backend() == "nccl":
+                dist.all_reduce(counters, op=dist.ReduceOp.SUM)  # the only collective: O(KiB) of int64 over RCCL
+            else:
+                host = counters.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM)
+                counters.copy_(host)
 
     run_once()                                                   # warm-up (twiddle tables, kernels)
     torch.cuda.synchronize()
@@ -86,7 +99,7 @@ def main():
         dist.barrier()
     elapsed = (time.perf_counter() - t0) / args.repeat
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=("cuda" if dist.get_backend() == "nccl" else "cpu"))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     c = counters.cpu().tolist()
