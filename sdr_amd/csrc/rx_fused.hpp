@@ -16,10 +16,17 @@
 // Built with -ffp-contract=off, so every product and sum rounds separately as on the CPU.
 //
 // Mapping: TPS = N/E threads per symbol; a workgroup is max(64, TPS) threads = 64/TPS symbols
-// (small N) or one symbol (N >= 1024).  Workgroups are persistent and stride over the batch.
+// (small N) or one symbol (N >= 1024) and handles a short run of consecutive symbol groups.
 // Twiddles: first pass = lane-uniform (scalar registers), middle pass = small LDS table, last
 // pass = per-thread registers loaded once per workgroup.
 // HBM traffic per symbol: 8*N bytes read (CP never fetched) + 4*N*bps bytes of LLR written.
+//
+// Instantiations <LOG2N, MI, MQ, FULL, EQ>: MI/MQ = bits on the I/Q axis (0,0 = FFT only);
+// FULL = hard bits / bins / counters optional at run time; EQ = per-subcarrier taps / weights
+// held in registers.  Compile-time experiment switches kept for A/B measurements (all measured
+// neutral or worse): SDR_WPE=<n> (force waves per SIMD), SDR_PREFETCH
+// (load the next symbol before storing this one), SDR_NT_LOADS (non-temporal sample loads),
+// SDR_NO_STAGE8 / SDR_NO_STG_ALIAS (LLR staging variants).  Run-time knobs: see RxTuning.
 #pragma once
 
 #include <hip/hip_runtime.h>
