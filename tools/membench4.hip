@@ -70,6 +70,22 @@ __global__ void __launch_bounds__(256) s3(const v4f* __restrict__ in, v4f* __res
     __builtin_nontemporal_store(v, out + (2 * g) * 64 + lane);
     __builtin_nontemporal_store(v, out + (2 * g + 1) * 64 + lane);
 }
+// read-only and write-only row-granular streams, for reference
+__global__ void __launch_bounds__(256) rd_only(const v4f* __restrict__ in, v4f* __restrict__ out, unsigned long long rows)
+{
+    const unsigned long long g = (unsigned long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    v4f acc = {0, 0, 0, 0};
+    for (int i = 0; i < 8; ++i) { const unsigned long long r = g * 8 + i; if (r < rows) acc += in[r * 64 + lane]; }
+    if (acc.x == 12345.678f) out[lane] = acc;           // never true: keeps the loads alive
+}
+__global__ void __launch_bounds__(256) wr_only(v4f* __restrict__ out, unsigned long long rows)
+{
+    const unsigned long long g = (unsigned long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const v4f v = {1.f, 2.f, 3.f, (float)g};
+    for (int i = 0; i < 8; ++i) { const unsigned long long r = g * 8 + i; if (r < rows) __builtin_nontemporal_store(v, out + r * 64 + lane); }
+}
 template <typename F> float timeit(F&& f)
 {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -91,6 +107,14 @@ int main()
 #define RUN1(W, R) report("S1 shared symbols, " #W " waves/WG, remap " #R, timeit([&] { s1<W, R><<<(unsigned)((n_sym + 2 * W - 1) / (2 * W)), 64 * W>>>((const v4f*)in, (v4f*)out, n_sym); }))
         RUN0(1, 1); RUN0(1, 0); RUN0(4, 1); RUN0(4, 0);
         RUN1(4, 1); RUN1(4, 0); RUN1(8, 1); RUN1(8, 0); RUN1(16, 0);
+        {
+            const unsigned long long rows = out_bytes / 1024;
+            const unsigned grid = (unsigned)((rows / 8 + 3) / 4);
+            float ms = timeit([&] { rd_only<<<grid, 256>>>((const v4f*)out, (v4f*)in, rows); });
+            printf("%-44s %7.3f ms %7.1f GB/s\n", "read only, 8 rows per wave", ms, (double)out_bytes / ms / 1e6);
+            ms = timeit([&] { wr_only<<<grid, 256>>>((v4f*)out, rows); });
+            printf("%-44s %7.3f ms %7.1f GB/s\n", "write only (NT), 8 rows per wave", ms, (double)out_bytes / ms / 1e6);
+        }
         report("S3 row-granular grid", timeit([&] { s3<<<(unsigned)((n_sym * IN_ROWS + 3) / 4), 256>>>((const v4f*)in, (v4f*)out, n_sym); }));
     }
     return 0;
