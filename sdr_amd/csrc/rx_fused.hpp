@@ -713,15 +713,18 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) SDR_WAVES_ATTR rx_fused_k
 // what the benchmarks and tests run):
 //   SDR_GROUPS_PER_WG  symbol groups per workgroup (0 = one resident grid striding over the batch)
 //   SDR_XCD_WINDOW     window of the XCD-aware workgroup-id permutation (0 = off)
+//   SDR_LDS_PAD        bytes of unused dynamic LDS per workgroup (occupancy experiments)
 //   SDR_DEBUG          print each instantiation's launch shape once
 struct RxTuning {
     long groups_per_wg = -1;      // -1: default
     long xcd_window = 4096;
+    long lds_pad = 0;             // extra dynamic LDS per workgroup: throttles resident workgroups per CU
     bool debug = false;
     RxTuning()
     {
         if (const char* v = getenv("SDR_GROUPS_PER_WG")) groups_per_wg = atol(v);
         if (const char* v = getenv("SDR_XCD_WINDOW")) xcd_window = atol(v) & ~7L;
+        if (const char* v = getenv("SDR_LDS_PAD")) lds_pad = atol(v);
         debug = getenv("SDR_DEBUG") != nullptr;
     }
 };
@@ -747,7 +750,7 @@ int launch_rx_fused(sdr_ctx* ctx, const RxParams& p)
     if (tune.groups_per_wg >= 0) per_wg = static_cast<unsigned long long>(tune.groups_per_wg);
     if (per_wg == 0 || tune.debug) {
         int nb = 0;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, O::kWG, 0);
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, O::kWG, static_cast<size_t>(tune.lds_pad > 0 ? tune.lds_pad : 0));
         if (e != hipSuccess) return fail_hip(e, "hipOccupancyMaxActiveBlocksPerMultiprocessor");
         if (nb < 1) nb = 1;
         if (tune.debug) fprintf(stderr, "[sdr] rx_fused<%d,%d,%d,%d,%d>: %d threads/WG, %d WG/CU, %d CUs\n", LOG2N, MI, MQ, int(FULL), int(EQ), O::kWG, nb, ctx->num_cu);
@@ -763,7 +766,7 @@ int launch_rx_fused(sdr_ctx* ctx, const RxParams& p)
     RxParams q = p;
     q.groups_per_wg = static_cast<uint32_t>(per_wg);
     q.xcd_window = static_cast<uint32_t>(tune.xcd_window > 0 ? tune.xcd_window : 0);
-    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(O::kWG), 0, ctx->stream, q);
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(O::kWG), static_cast<size_t>(tune.lds_pad > 0 ? tune.lds_pad : 0), ctx->stream, q);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(e, "rx_fused_kernel launch");
     return SDR_OK;
