@@ -17,6 +17,13 @@ int fft2_device(sdr_ctx* ctx, bool is_double, void* d_data, size_t n, size_t bat
     if (n <= 1 || batch == 0) return SDR_OK;                       // lib/inc/fft.hpp:91: sizes 0 and 1 pass untouched
     if (!is_pow2(n)) return fail(SDR_ERR_NOT_POW2, "%s", kPow2Message);
     if (!d_data) return fail(SDR_ERR_INVALID, "null device pointer");
+    // fp32 batches of a planned size run in place through the tuned kernels (a symbol is wholly in
+    // registers before any of it is written back): forward = receive kernel without prefix and
+    // demapper, inverse = transmit kernel without prefix
+    if (!is_double && rx_fused_supported(static_cast<uint32_t>(n <= 8192 ? n : 0), 0) && reinterpret_cast<uintptr_t>(d_data) % 16 == 0) {
+        if (!inverse) return rx_fft_only_launch(ctx, d_data, static_cast<uint32_t>(n), 0, batch, d_data);
+        if (tx_fused_ok(n, 0, d_data, d_data)) return tx_fused_launch(ctx, d_data, static_cast<uint32_t>(n), 0, batch, d_data);
+    }
     return is_double ? fft_generic_f64(ctx, d_data, d_data, n, inverse != 0, n, 0, n, 0, 0, batch)
                      : fft_generic_f32(ctx, d_data, d_data, n, inverse != 0, n, 0, n, 0, 0, batch);
 }

@@ -3,7 +3,7 @@
 
   python tools/kbench.py --cases 1024:4 1024:6 1024:0 4096:8 --symbols 262144 --steps 10
 
-case = n_fft:bps[:eq][:hard][:cnt]   (bps 0 = FFT only / ofdm::rx batch; eq = per-subcarrier
+case = n_fft:bps[:eq][:hard][:cnt]   (bps 0 = FFT only / ofdm::rx batch; bps 'fft' / 'ifft' = in-place fft::fft2 / ifft2 batch; eq = per-subcarrier
 equaliser sets; hard = also packed hard bits; cnt = error counters against reference bits)
 Inputs are random complex noise (values do not change the instruction stream).
 """
@@ -30,7 +30,8 @@ def main():
     results = {}
     for case in args.cases * args.repeat:
         parts = case.split(":")
-        n, bps = int(parts[0]), int(parts[1])
+        fft_only = parts[1] in ("fft", "ifft")
+        n, bps = int(parts[0]), (0 if fft_only else int(parts[1]))
         with_eq = "eq" in parts[2:]
         with_hard = "hard" in parts[2:]
         cp = n // 4
@@ -57,6 +58,9 @@ def main():
             out = torch.empty((n_sym, n, bps), dtype=torch.float32, device="cuda")
             step = lambda: ctx.demod(rx, n, cp, bps, eq=eq, llr_weight=(wgt if wgt is not None else 1.5), sym_per_set=per, out_llr=out,
                                      out_hard=hard, ref_hard=ref, counters=cnt)
+        elif fft_only:
+            buf = rx.view(-1)[: n_sym * n].view(n_sym, n)
+            step = lambda: ctx.fft2_(buf, inverse=(parts[1] == "ifft"))      # in place; values drift, timing does not care
         else:
             step = lambda: ctx.ofdm_rx(rx, n, cp)
         for _ in range(args.warmup):
