@@ -75,6 +75,48 @@ __global__ void pack_kernel(const uint16_t* __restrict__ index, size_t n_sym, in
     }
 }
 
+// from_constl in one pass (lib/inc/modulation.hpp:96-112 for any order).  A wave takes 512
+// consecutive symbols: lane-contiguous loads (1 KiB per instruction), hard decisions parked in a
+// per-wave LDS strip, then lane l packs symbols 8l .. 8l+7 = BPS whole bytes of the MSB-first
+// stream.  Nothing but the symbols is read and nothing but the bytes written (the two-kernel
+// form went through a 2-byte index array in HBM).
+template <typename T, int MI, int MQ>
+__global__ void __launch_bounds__(256) from_constl_kernel(const T* __restrict__ sym, size_t n_sym, T inorm, size_t n_bytes, uint8_t* __restrict__ out)
+{
+    constexpr int BPS = MI + MQ;
+    __shared__ __attribute__((aligned(16))) uint16_t strip[4][512];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint16_t* mine = strip[wave];
+    const size_t n_tiles = (n_sym + 511) / 512;
+    for (size_t tile = static_cast<size_t>(blockIdx.x) * 4 + wave; tile < n_tiles; tile += static_cast<size_t>(gridDim.x) * 4) {
+        const size_t k0 = tile * 512;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const size_t k = k0 + j * 64 + lane;
+            unsigned idx = 0;
+            if (k < n_sym) idx = demap_point<T, MI, MQ, false, true>(sym[2 * k], sym[2 * k + 1], inorm, T(0), nullptr);
+            mine[j * 64 + lane] = static_cast<uint16_t>(idx);
+        }
+        __builtin_amdgcn_wave_barrier();     // one wave: its LDS operations complete in order
+        unsigned long long lo = 0;           // bit stream of the group, MSB first: 8 * BPS <= 80 bits
+        unsigned hi = 0;                     // bits above 64 (1024-QAM only)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const unsigned idx = mine[lane * 8 + i];
+            if constexpr (8 * BPS > 64) hi = (hi << BPS) | static_cast<unsigned>(lo >> (64 - BPS));
+            lo = (lo << BPS) | idx;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const size_t first = (k0 / 8 + lane) * BPS;
+#pragma unroll
+        for (int b = 0; b < BPS; ++b) {
+            const int shift = 8 * (BPS - 1 - b);         // byte b holds stream bits [8b, 8b+8)
+            const unsigned v = shift >= 64 ? hi >> (shift - 64) : static_cast<unsigned>(lo >> shift);
+            if (first + b < n_bytes) out[first + b] = static_cast<uint8_t>(v);
+        }
+    }
+}
+
 template <int MI, int MQ>
 __global__ void soft_demap_kernel(const float* __restrict__ sym, size_t n_sym, float inorm, const float* __restrict__ wgt, float w0,
                                   float* __restrict__ llr)
@@ -213,10 +255,14 @@ int from_constl_dev(sdr_ctx* ctx, bool is_double, int mod, const void* d_sym, si
     const size_t n_bytes = (n_sym * static_cast<size_t>(mod)) / 8;
     if (n_bytes == 0) return SDR_OK;
     if (!d_sym || !d_bytes) return fail(SDR_ERR_INVALID, "null device pointer");
-    void* idx = nullptr;
-    SDR_TRY(get_staging(ctx, 1, n_sym * sizeof(uint16_t), &idx));
-    SDR_TRY(launch_nearest(ctx, is_double, mod, d_sym, n_sym, static_cast<uint16_t*>(idx)));
-    hipLaunchKernelGGL(pack_kernel, dim3(grid_for(ctx, n_bytes)), dim3(kThreads), 0, ctx->stream, static_cast<const uint16_t*>(idx), n_sym, mod, n_bytes, d_bytes);
+    const unsigned grid = grid_for(ctx, (n_sym + 7) / 8);
+    static_assert(kThreads == 256, "from_constl_kernel is written for four waves per workgroup");
+    dispatch_mod(mod, [&]<int MI, int MQ>() {
+        if (is_double)
+            hipLaunchKernelGGL((from_constl_kernel<double, MI, MQ>), dim3(grid), dim3(kThreads), 0, ctx->stream, static_cast<const double*>(d_sym), n_sym, inorm_in<double>(mod), n_bytes, d_bytes);
+        else
+            hipLaunchKernelGGL((from_constl_kernel<float, MI, MQ>), dim3(grid), dim3(kThreads), 0, ctx->stream, static_cast<const float*>(d_sym), n_sym, inorm_in<float>(mod), n_bytes, d_bytes);
+    });
     SDR_HIP(hipGetLastError());
     return SDR_OK;
 }
