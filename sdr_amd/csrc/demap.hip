@@ -35,20 +35,39 @@ __device__ inline unsigned stream_bits(const uint8_t* __restrict__ s, size_t pos
     return (acc >> shift) & ((1u << nbits) - 1u);
 }
 
+// to_constl (lib/inc/modulation.hpp:78-94 for any order): a thread maps two consecutive symbols,
+// so that a lane's store is 16 bytes (fp32) and a wave instruction writes 1 KiB contiguous;
+// the output is written once and never re-read here: non-temporal.
 template <typename T, int MI, int MQ>
-__global__ void to_constl_kernel(const uint8_t* __restrict__ bytes, size_t n_sym, T norm, T* __restrict__ out)
+__global__ void to_constl_kernel(const uint8_t* __restrict__ bytes, size_t n_sym, T norm, T* __restrict__ out, bool wide_ok)
 {
     constexpr int BPS = MI + MQ;
-    for (size_t k = blockIdx.x * size_t(blockDim.x) + threadIdx.x; k < n_sym; k += size_t(gridDim.x) * blockDim.x) {
-        const unsigned idx = stream_bits(bytes, k * BPS, BPS);
-        const unsigned gi = idx >> MQ, gq = idx & ((1u << MQ) - 1u);
-        T li = T(0), lq = T(0);
+    typedef T vec4 __attribute__((ext_vector_type(4)));
+    const size_t n_pairs = (n_sym + 1) / 2;
+    for (size_t pr = blockIdx.x * size_t(blockDim.x) + threadIdx.x; pr < n_pairs; pr += size_t(gridDim.x) * blockDim.x) {
+        T v[4] = {T(0), T(0), T(0), T(0)};
 #pragma unroll
-        for (unsigned g = 0; g < (1u << MI); ++g) li = (g == gi) ? axis_level<T, MI>(g) : li;
+        for (int h = 0; h < 2; ++h) {
+            const size_t k = 2 * pr + h;
+            if (k >= n_sym) break;
+            const unsigned idx = stream_bits(bytes, k * BPS, BPS);
+            const unsigned gi = idx >> MQ, gq = idx & ((1u << MQ) - 1u);
+            T li = T(0), lq = T(0);
 #pragma unroll
-        for (unsigned g = 0; g < (1u << MQ); ++g) lq = (g == gq) ? axis_level<T, MQ>(g) : lq;
-        out[2 * k] = li * norm;        // table[idx] * norm: complex * real (modulation.hpp:90-91)
-        out[2 * k + 1] = lq * norm;
+            for (unsigned g = 0; g < (1u << MI); ++g) li = (g == gi) ? axis_level<T, MI>(g) : li;
+#pragma unroll
+            for (unsigned g = 0; g < (1u << MQ); ++g) lq = (g == gq) ? axis_level<T, MQ>(g) : lq;
+            v[2 * h] = li * norm;          // table[idx] * norm: complex * real (modulation.hpp:90-91)
+            v[2 * h + 1] = lq * norm;
+        }
+        if (wide_ok && 2 * pr + 1 < n_sym) {
+            const vec4 q = {v[0], v[1], v[2], v[3]};
+            __builtin_nontemporal_store(q, reinterpret_cast<vec4*>(out + 4 * pr));
+        } else {
+            out[4 * pr] = v[0];
+            out[4 * pr + 1] = v[1];
+            if (2 * pr + 1 < n_sym) { out[4 * pr + 2] = v[2]; out[4 * pr + 3] = v[3]; }
+        }
     }
 }
 
@@ -217,12 +236,12 @@ int to_constl_dev(sdr_ctx* ctx, bool is_double, int mod, const uint8_t* d_bytes,
     if (!valid_mod(mod)) return fail(SDR_ERR_INVALID, "unknown modulation %d", mod);
     if (n_sym == 0) return SDR_OK;
     if (!d_bytes || !d_out) return fail(SDR_ERR_INVALID, "null device pointer");
-    const unsigned grid = grid_for(ctx, n_sym);
+    const unsigned grid = grid_for(ctx, (n_sym + 1) / 2);
     dispatch_mod(mod, [&]<int MI, int MQ>() {
         if (is_double)
-            hipLaunchKernelGGL((to_constl_kernel<double, MI, MQ>), dim3(grid), dim3(kThreads), 0, ctx->stream, d_bytes, n_sym, norm_in<double>(mod), static_cast<double*>(d_out));
+            hipLaunchKernelGGL((to_constl_kernel<double, MI, MQ>), dim3(grid), dim3(kThreads), 0, ctx->stream, d_bytes, n_sym, norm_in<double>(mod), static_cast<double*>(d_out), reinterpret_cast<uintptr_t>(d_out) % 32 == 0);
         else
-            hipLaunchKernelGGL((to_constl_kernel<float, MI, MQ>), dim3(grid), dim3(kThreads), 0, ctx->stream, d_bytes, n_sym, norm_in<float>(mod), static_cast<float*>(d_out));
+            hipLaunchKernelGGL((to_constl_kernel<float, MI, MQ>), dim3(grid), dim3(kThreads), 0, ctx->stream, d_bytes, n_sym, norm_in<float>(mod), static_cast<float*>(d_out), reinterpret_cast<uintptr_t>(d_out) % 16 == 0);
     });
     SDR_HIP(hipGetLastError());
     return SDR_OK;
