@@ -11,8 +11,64 @@
 static int g_failed = 0;
 #define CHECK(cond) do { if (!(cond)) { std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); ++g_failed; } } while (0)
 
+// The reference's own nine cases (lib/tests/sliding_buffer_test.cpp:11-154), restated: same
+// inputs, same expected windows.
+static void reference_cases()
+{
+    using utils::sliding_buffer;
+    { sliding_buffer<int> b(5); CHECK(b.size() == 5u); }                                   // ConstructWithSize (:11-15)
+    {                                                                                       // IndexOutOfBounds (:21-28)
+        sliding_buffer<int> b(3);
+        auto r = b.at(3);
+        CHECK(!r.has_value());
+        CHECK(r.error().find("exceeds size") != std::string::npos);
+    }
+    {                                                                                       // PushSingleElement (:34-43)
+        sliding_buffer<int> b(4);
+        b.push_back(42);
+        auto v = b.at(3);
+        CHECK(v.has_value() && *v == 42);
+    }
+    {                                                                                       // PushRangeNoWrap (:49-60)
+        sliding_buffer<int> b(5);
+        std::vector<int> src{1, 2, 3};
+        b.push_back(src.begin(), src.end());
+        CHECK(b[2] == 1 && b[3] == 2 && b[4] == 3);
+    }
+    {                                                                                       // PushRangeExactFit (:66-77)
+        sliding_buffer<int> b(4);
+        std::vector<int> src{10, 20, 30, 40};
+        b.push_back(src.begin(), src.end());
+        CHECK(b[0] == 10 && b[1] == 20 && b[2] == 30 && b[3] == 40);
+    }
+    {                                                                                       // PushRangeWithWrap (:83-100)
+        sliding_buffer<int> b(5);
+        std::vector<int> first{1, 2, 3, 4}, second{5, 6, 7};
+        b.push_back(first.begin(), first.end());
+        b.push_back(second.begin(), second.end());
+        CHECK(b[0] == 3 && b[1] == 4 && b[2] == 5 && b[3] == 6 && b[4] == 7);
+    }
+    {                                                                                       // OverwriteOldestData (:106-116)
+        sliding_buffer<int> b(3);
+        std::vector<int> src{1, 2, 3, 4, 5};
+        b.push_back(src.begin(), src.end());
+        CHECK(b[0] == 3 && b[1] == 4 && b[2] == 5);
+    }
+    {                                                                                       // MultipleSmallPushes (:122-136)
+        sliding_buffer<int> b(4);
+        for (int v = 1; v <= 5; ++v) b.push_back(v);
+        CHECK(b[0] == 2 && b[1] == 3 && b[2] == 4 && b[3] == 5);
+    }
+    {                                                                                       // IndexIsRelativeToCurrentHead (:142-154)
+        sliding_buffer<int> b(3);
+        for (int v : {10, 20, 30, 40}) b.push_back(v);
+        CHECK(b[0] == 20 && b[1] == 30 && b[2] == 40);
+    }
+}
+
 int main()
 {
+    reference_cases();
     utils::sliding_buffer<int> b(5);
     CHECK(b.size() == 5);
     for (std::size_t i = 0; i < 5; ++i) CHECK(b[i] == 0);                  // zero filled (:52-54)
