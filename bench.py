@@ -163,7 +163,7 @@ def time_workload(ctx, torch, dist, name, steps, warmup, world, rank, n_sym_over
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="fft1024_16qam_1M", choices=sorted(WORKLOADS))
     ap.add_argument("--symbols", type=int, default=0, help="override symbols per GPU (debug)")
