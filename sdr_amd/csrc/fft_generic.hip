@@ -41,42 +41,55 @@ __device__ inline void butterfly(typename Vec2<T>::type& even, typename Vec2<T>:
     odd.x = br; odd.y = bi;
 }
 
+// One sequence per `tps` threads, blockDim.x / tps sequences per workgroup (short sequences would
+// otherwise leave most of a wave idle: the reference's own tests and demo use n = 8).
 template <typename T>
 __global__ void __launch_bounds__(256) fft_lds_kernel(const typename Vec2<T>::type* __restrict__ in,
                                                       typename Vec2<T>::type* __restrict__ out,
                                                       const typename Vec2<T>::type* __restrict__ tw,
-                                                      unsigned log2n, FftGeom<T> g)
+                                                      unsigned log2n, unsigned tps, FftGeom<T> g)
 {
     using V = typename Vec2<T>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    V* buf = reinterpret_cast<V*>(lds_raw);
     const unsigned n = 1u << log2n;
-    const unsigned tid = threadIdx.x;
-    for (size_t seq = blockIdx.x; seq < g.n_seq; seq += gridDim.x) {
-        const V* src = in + seq * g.in_stride + g.in_offset;
-        for (unsigned i = tid; i < n; i += blockDim.x) {
-            const unsigned r = log2n ? (__brev(i) >> (32u - log2n)) : 0u;
-            buf[r] = src[i];
+    const unsigned spw = blockDim.x / tps;                 // sequences per workgroup
+    const unsigned sub = threadIdx.x / tps;
+    const unsigned tid = threadIdx.x - sub * tps;
+    V* buf = reinterpret_cast<V*>(lds_raw) + static_cast<size_t>(sub) * n;
+    const size_t n_groups = (g.n_seq + spw - 1) / spw;
+    for (size_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        const size_t seq = grp * spw + sub;
+        const bool valid = seq < g.n_seq;                  // barriers below are reached by every thread
+        if (valid) {
+            const V* src = in + seq * g.in_stride + g.in_offset;
+            for (unsigned i = tid; i < n; i += tps) {
+                const unsigned r = log2n ? (__brev(i) >> (32u - log2n)) : 0u;
+                buf[r] = src[i];
+            }
         }
         for (unsigned c = 0; c < log2n; ++c) {
             __syncthreads();
             const unsigned half = 1u << c;
-            for (unsigned b = tid; b < (n >> 1); b += blockDim.x) {
-                const unsigned j = b & (half - 1u);
-                const unsigned pos = ((b >> c) << (c + 1u)) | j;
-                V e = buf[pos], o = buf[pos + half];
-                butterfly<T>(e, o, tw[half - 1u + j]);
-                buf[pos] = e;
-                buf[pos + half] = o;
+            if (valid) {
+                for (unsigned b = tid; b < (n >> 1); b += tps) {
+                    const unsigned j = b & (half - 1u);
+                    const unsigned pos = ((b >> c) << (c + 1u)) | j;
+                    V e = buf[pos], o = buf[pos + half];
+                    butterfly<T>(e, o, tw[half - 1u + j]);
+                    buf[pos] = e;
+                    buf[pos + half] = o;
+                }
             }
         }
         __syncthreads();
-        V* dst = out + seq * g.out_stride;
-        for (unsigned i = tid; i < n; i += blockDim.x) {
-            V v = buf[i];
-            if (g.divisor != T(0)) { v.x /= g.divisor; v.y /= g.divisor; }
-            dst[g.out_offset + i] = v;
-            if (i + g.cp_fill >= n) dst[i + g.cp_fill - n] = v;   // cyclic prefix = copy of the tail
+        if (valid) {
+            V* dst = out + seq * g.out_stride;
+            for (unsigned i = tid; i < n; i += tps) {
+                V v = buf[i];
+                if (g.divisor != T(0)) { v.x /= g.divisor; v.y /= g.divisor; }
+                dst[g.out_offset + i] = v;
+                if (i + g.cp_fill >= n) dst[i + g.cp_fill - n] = v;   // cyclic prefix = copy of the tail
+            }
         }
         __syncthreads();
     }
@@ -156,15 +169,22 @@ static int run_fft(sdr_ctx* ctx, const void* d_in, void* d_out, size_t n, bool i
     const bool aliased = (d_in == d_out);
     if (lds_bytes <= lds_cap) {
         auto kern = fft_lds_kernel<T>;
-        if (lds_bytes > 48 * 1024)
-            SDR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes)));
-        size_t blocks = n_seq;
+        unsigned tps = n / 2 < 256 ? static_cast<unsigned>(n / 2) : 256u;     // threads per sequence
+        if (tps == 0) tps = 1;
+        unsigned threads = 256;
+        if (static_cast<size_t>(threads / tps) > n_seq) {                   // few sequences: a smaller workgroup
+            threads = static_cast<unsigned>(n_seq) * tps;
+            if (threads < 64) threads = 64 / tps * tps;
+        }
+        const unsigned spw = threads / tps;
+        const size_t lds_total = lds_bytes * spw;
+        if (lds_total > 48 * 1024)
+            SDR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_total)));
+        size_t blocks = (n_seq + spw - 1) / spw;
         const size_t cap = size_t(ctx->num_cu) * 16;
         if (blocks > cap) blocks = cap;
-        unsigned threads = 256;
-        if (n / 2 < threads) threads = n / 2 < 64 ? 64 : static_cast<unsigned>(n / 2);
-        hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(threads), lds_bytes, ctx->stream,
-                           static_cast<const V*>(d_in), static_cast<V*>(d_out), static_cast<const V*>(tw), log2n, g);
+        hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(threads), lds_total, ctx->stream,
+                           static_cast<const V*>(d_in), static_cast<V*>(d_out), static_cast<const V*>(tw), log2n, tps, g);
         SDR_HIP(hipGetLastError());
         return SDR_OK;
     }

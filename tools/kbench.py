@@ -30,7 +30,7 @@ def main():
     results = {}
     for case in args.cases * args.repeat:
         parts = case.split(":")
-        fft_only = parts[1] in ("fft", "ifft")
+        fft_only = parts[1] in ("fft", "ifft", "fft64")
         n, bps = int(parts[0]), (0 if fft_only else int(parts[1]))
         with_eq = "eq" in parts[2:]
         with_hard = "hard" in parts[2:]
@@ -60,6 +60,10 @@ def main():
                                      out_hard=hard, ref_hard=ref, counters=cnt)
         elif fft_only:
             buf = rx.view(-1)[: n_sym * n].view(n_sym, n)
+            if parts[1] == "fft64":                                          # fp64 generic engine: 16 bytes per point each way
+                buf = buf[: n_sym // 2].to(torch.complex128)
+                bytes_sym = 32 * n
+                n_sym = n_sym // 2
             step = lambda: ctx.fft2_(buf, inverse=(parts[1] == "ifft"))      # in place; values drift, timing does not care
         else:
             step = lambda: ctx.ofdm_rx(rx, n, cp)
