@@ -44,7 +44,7 @@ __device__ inline void butterfly(typename Vec2<T>::type& even, typename Vec2<T>:
 // One sequence per `tps` threads, blockDim.x / tps sequences per workgroup (short sequences would
 // otherwise leave most of a wave idle: the reference's own tests and demo use n = 8).
 template <typename T>
-__global__ void __launch_bounds__(256) fft_lds_kernel(const typename Vec2<T>::type* __restrict__ in,
+__global__ void __launch_bounds__(1024) fft_lds_kernel(const typename Vec2<T>::type* __restrict__ in,
                                                       typename Vec2<T>::type* __restrict__ out,
                                                       const typename Vec2<T>::type* __restrict__ tw,
                                                       unsigned log2n, unsigned tps, FftGeom<T> g)
@@ -67,17 +67,36 @@ __global__ void __launch_bounds__(256) fft_lds_kernel(const typename Vec2<T>::ty
                 buf[r] = src[i];
             }
         }
-        for (unsigned c = 0; c < log2n; ++c) {
+        // Stages are taken two at a time: a thread holds the four positions that differ in bits c
+        // and c+1 and runs the four literal radix-2 butterflies of both stages on them (same
+        // operations and twiddles as one stage at a time; half the barriers and LDS round trips).
+        unsigned c = 0;
+        if (log2n & 1u) {                                  // odd number of stages: the first one alone
+            __syncthreads();
+            if (valid) {
+                for (unsigned b = tid; b < (n >> 1); b += tps) {
+                    V e = buf[2 * b], o = buf[2 * b + 1];
+                    butterfly<T>(e, o, tw[0]);
+                    buf[2 * b] = e;
+                    buf[2 * b + 1] = o;
+                }
+            }
+            c = 1;
+        }
+        for (; c + 1 < log2n; c += 2) {
             __syncthreads();
             const unsigned half = 1u << c;
             if (valid) {
-                for (unsigned b = tid; b < (n >> 1); b += tps) {
-                    const unsigned j = b & (half - 1u);
-                    const unsigned pos = ((b >> c) << (c + 1u)) | j;
-                    V e = buf[pos], o = buf[pos + half];
-                    butterfly<T>(e, o, tw[half - 1u + j]);
-                    buf[pos] = e;
-                    buf[pos + half] = o;
+                for (unsigned q = tid; q < (n >> 2); q += tps) {
+                    const unsigned j = q & (half - 1u);
+                    const unsigned p0 = ((q >> c) << (c + 2u)) | j;
+                    V a0 = buf[p0], a1 = buf[p0 + half], a2 = buf[p0 + 2u * half], a3 = buf[p0 + 3u * half];
+                    const V w0 = tw[half - 1u + j];                       // stage c, index j for both pairs
+                    butterfly<T>(a0, a1, w0);
+                    butterfly<T>(a2, a3, w0);
+                    butterfly<T>(a0, a2, tw[2u * half - 1u + j]);         // stage c+1, index j
+                    butterfly<T>(a1, a3, tw[2u * half - 1u + j + half]);  // stage c+1, index j + 2^c
+                    buf[p0] = a0; buf[p0 + half] = a1; buf[p0 + 2u * half] = a2; buf[p0 + 3u * half] = a3;
                 }
             }
         }
@@ -169,9 +188,13 @@ static int run_fft(sdr_ctx* ctx, const void* d_in, void* d_out, size_t n, bool i
     const bool aliased = (d_in == d_out);
     if (lds_bytes <= lds_cap) {
         auto kern = fft_lds_kernel<T>;
-        unsigned tps = n / 2 < 256 ? static_cast<unsigned>(n / 2) : 256u;     // threads per sequence
+        // threads per sequence: one per butterfly for short sequences; long ones (whose LDS footprint
+        // leaves room for one or two workgroups per CU) get up to 1024 so that the CU is not left
+        // with four waves
+        unsigned tps = n / 2 < 256 ? static_cast<unsigned>(n / 2) : 256u;
         if (tps == 0) tps = 1;
-        unsigned threads = 256;
+        if (lds_bytes >= 32 * 1024) tps = n / 4 < 1024 ? static_cast<unsigned>(n / 4) : 1024u;
+        unsigned threads = tps > 256 ? tps : 256;
         if (static_cast<size_t>(threads / tps) > n_seq) {                   // few sequences: a smaller workgroup
             threads = static_cast<unsigned>(n_seq) * tps;
             if (threads < 64) threads = 64 / tps * tps;
