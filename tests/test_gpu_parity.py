@@ -421,6 +421,29 @@ def test_pipe_equals_one_shot_demod(ctx, oracle, n, cp, bps, chunk, depth):
     assert same(np.concatenate(hard), ref["hard"])
 
 
+def test_pipe_with_taps_and_weights(ctx, oracle):
+    """The pipe's equaliser sets restart at every chunk (set 0 = the chunk's first symbol)."""
+    from sdr_amd.link import noise_sigma
+    from sdr_amd.pipe import Pipe
+    n, cp, bps, per, chunk = 256, 64, 6, 4, 12
+    rng = np.random.default_rng(8)
+    n_sets = chunk // per
+    h = (rand_c(rng, (n_sets, n)) * np.float32(np.sqrt(0.5))).astype(np.complex64)
+    h[np.abs(h) < 0.2] += np.float32(0.4)
+    taps, wgt = oracle.zf_taps(bps, h, 30.0)
+    d_taps, d_wgt = dev(taps.ravel()), dev(wgt.ravel())
+    n_chunks = 5
+    rx = [oracle.link_generate(n, cp, bps, 5, c * chunk, chunk, np.float32(noise_sigma(n, bps, 30.0)), chan=h, sym_per_set=per)[0].reshape(chunk, n + cp)
+          for c in range(n_chunks)]
+    with Pipe(0, n_fft=n, cp=cp, mod=bps, chunk_symbols=chunk, depth=2, llr_to_host=True, hard_to_host=True,
+              sym_per_set=per, d_eq=d_taps.data_ptr(), d_llr_weight=d_wgt.data_ptr()) as pipe:
+        got = [(c.llr.copy(), c.hard.copy()) for c in pipe.run(rx)]
+    assert len(got) == n_chunks
+    for x, (llr, hard) in zip(rx, got):
+        ref = oracle.demod(x, n, cp, bps, eq=taps, weight=wgt, sym_per_set=per, want_fft=False)
+        assert same(llr, ref["llr"]) and same(hard, ref["hard"])
+
+
 def test_pipe_protocol_errors(ctx):
     from sdr_amd import capi
     from sdr_amd.pipe import Pipe
