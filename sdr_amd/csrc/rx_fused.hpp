@@ -374,8 +374,8 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 #endif
 
 // MI + MQ == 0: FFT only (bins to p.fft).  FULL: every output optional at run time.
-// EQ: per-subcarrier taps / LLR weights may be given; they are fetched before the transform so
-// that their latency hides under it (costs registers, hence a separate instantiation).
+// EQ: per-subcarrier taps / LLR weights may be given; they live in registers across the symbols of
+// a set (costs registers, hence a separate instantiation).
 template <int LOG2N, int MI, int MQ, bool FULL, bool EQ>
 __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) SDR_WAVES_ATTR rx_fused_kernel(const RxParams p)
 {
