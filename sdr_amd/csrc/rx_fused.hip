@@ -76,7 +76,8 @@ int rx_fused_launch(sdr_ctx* ctx, const sdr_demod_args& a)
     p.w0 = a.llr_weight0;
     p.inorm = std::sqrt(static_cast<float>(grid_energy(static_cast<int>(a.mod))));
     const bool full = a.d_hard || a.d_fft || a.d_counters || !a.d_llr || a.mod == 1;
-    const int variant = (full ? 2 : 0) | ((a.d_eq || a.d_llr_weight) ? 1 : 0);
+    const bool hard_only = a.d_hard && !a.d_llr && !a.d_fft && !a.d_counters && !a.d_eq && a.mod != 1;   // weights do not matter to nearest()
+    const int variant = hard_only ? 4 : (full ? 2 : 0) | ((a.d_eq || a.d_llr_weight) ? 1 : 0);
     SDR_TRY(dispatch(ctx, ilog2(a.n_fft), p, static_cast<int>(a.mod), variant));
     if (a.d_counters) SDR_TRY(fold_counters(ctx, reinterpret_cast<unsigned long long*>(a.d_counters), a.n_sym * a.n_fft, a.mod, a.n_sym));
     return SDR_OK;

@@ -370,13 +370,15 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 // N = 8192 (E = 32): FULL variants are held to one workgroup per CU by LDS and the tap-holding ones
 // would spill (measured 49 -> 33 %); the others fit two if
 // they stay within 256 registers.
-#define SDR_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(LOG2N >= 13 ? ((FULL || EQ) ? 1 : 2) : ((EQ || FULL) ? SDR_EQ_WPE : 1))))
+#define SDR_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(LOG2N >= 13 ? ((FULL || EQ || HARDONLY) ? 1 : 2) : ((EQ || FULL) ? SDR_EQ_WPE : 1))))
 #endif
 
 // MI + MQ == 0: FFT only (bins to p.fft).  FULL: every output optional at run time.
 // EQ: per-subcarrier taps / LLR weights may be given; they live in registers across the symbols of
 // a set (costs registers, hence a separate instantiation).
-template <int LOG2N, int MI, int MQ, bool FULL, bool EQ>
+// HARDONLY: packed hard decisions are the only output (the reference's own chain ofdm::rx ->
+// from_constl, lib/inc/ofdm.hpp:37-43 + modulation.hpp:96-112): no LLR arithmetic at all.
+template <int LOG2N, int MI, int MQ, bool FULL, bool EQ, bool HARDONLY = false>
 __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) SDR_WAVES_ATTR rx_fused_kernel(const RxParams p)
 {
     using O = PlanOps<LOG2N>;
@@ -388,11 +390,13 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) SDR_WAVES_ATTR rx_fused_k
     constexpr int DATA_BYTES = SYM_BYTES * SPW;
     constexpr int TW_BYTES = O::kMidCount * 8;
     using idx_t = std::conditional_t<(BPS > 8), uint16_t, uint8_t>;      // one hard decision
-    constexpr int IDX_BYTES = (FULL && DEMAP) ? N * SPW * static_cast<int>(sizeof(idx_t)) : 0;
+    static_assert(!(HARDONLY && (FULL || EQ || !DEMAP)), "HARDONLY is a variant of its own");
+    constexpr bool HARD_PATH = (FULL || HARDONLY) && DEMAP;          // hard decisions pass through LDS and are packed
+    constexpr int IDX_BYTES = HARD_PATH ? N * SPW * static_cast<int>(sizeof(idx_t)) : 0;
     constexpr int REF_SYM_BYTES = N * (DEMAP ? BPS : 8) / 8;      // reference bits of one symbol
     constexpr int REF_BYTES = (FULL && DEMAP) ? REF_SYM_BYTES * SPW : 0;
     constexpr int CHUNK = O::kGroupOut * BPS;                      // LLR floats per lane per output block
-    constexpr bool STAGE = DEMAP && SPW == 1 && stage_wanted(CHUNK);
+    constexpr bool STAGE = DEMAP && !HARDONLY && SPW == 1 && stage_wanted(CHUNK);
     constexpr int STG_STRIDE = stage_stride_bytes(CHUNK);
     constexpr int STG_WAVE_BYTES = STAGE ? 64 * STG_STRIDE : 0;
     constexpr int STG_BYTES = STG_WAVE_BYTES * (O::kWG / 64);
@@ -598,7 +602,7 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) SDR_WAVES_ATTR rx_fused_k
                             else w = p.wgt[tap_set * N + k + g];
                         }
                     }
-                    idx[g] = demap_point<float, MI, MQ, true, FULL>(y.x, y.y, p.inorm, w, l + g * BPS);
+                    idx[g] = demap_point<float, MI, MQ, !HARDONLY, HARD_PATH>(y.x, y.y, p.inorm, w, l + g * BPS);
                 });
                 if constexpr (STAGE) {
                     if (p.llr && active) {
@@ -624,12 +628,12 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) SDR_WAVES_ATTR rx_fused_k
                         });
                         __builtin_amdgcn_wave_barrier();
                     }
-                } else {
+                } else if constexpr (!HARDONLY) {
                     if (p.llr && active) store_floats<GO * BPS>(p.llr + (bin0 + k) * BPS, l);
                 }
-                if constexpr (FULL) {
-                    if (p.hard) static_for<GO>([&](auto G) { constexpr int g = G; lds_idx[slot * N + k + g] = static_cast<idx_t>(idx[g]); });
-                    if (p.counters && active) {
+                if constexpr (HARD_PATH) {
+                    if (HARDONLY || p.hard) static_for<GO>([&](auto G) { constexpr int g = G; lds_idx[slot * N + k + g] = static_cast<idx_t>(idx[g]); });
+                    if constexpr (FULL) if (p.counters && active) {
                         // GO adjacent points: GO * BPS <= 20 reference bits starting at a multiple of
                         // GO * BPS bits, i.e. inside a four-byte window that starts at the bit's byte
                         static_assert(GO * BPS <= 25, "reference bits of one register group fit a four-byte window");
@@ -666,8 +670,8 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) SDR_WAVES_ATTR rx_fused_k
                     }
                 }
             });
-            if constexpr (FULL) {
-                if (p.hard) {
+            if constexpr (HARD_PATH) {
+                if (HARDONLY || p.hard) {
                     __syncthreads();
                     constexpr int WORDS = N * BPS / 32;
                     constexpr int CNT = (32 + BPS - 1) / BPS + 1;
@@ -734,11 +738,11 @@ inline const RxTuning& rx_tuning()
     return t;
 }
 
-template <int LOG2N, int MI, int MQ, bool FULL, bool EQ>
+template <int LOG2N, int MI, int MQ, bool FULL, bool EQ, bool HARDONLY = false>
 int launch_rx_fused(sdr_ctx* ctx, const RxParams& p)
 {
     using O = PlanOps<LOG2N>;
-    auto kern = rx_fused_kernel<LOG2N, MI, MQ, FULL, EQ>;
+    auto kern = rx_fused_kernel<LOG2N, MI, MQ, FULL, EQ, HARDONLY>;
     const RxTuning& tune = rx_tuning();
     const unsigned long long n_groups = (p.n_sym + O::kSPW - 1) / O::kSPW;
     // Each workgroup takes a run of consecutive symbol groups.  Short runs (many workgroups, the
@@ -753,7 +757,7 @@ int launch_rx_fused(sdr_ctx* ctx, const RxParams& p)
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, O::kWG, static_cast<size_t>(tune.lds_pad > 0 ? tune.lds_pad : 0));
         if (e != hipSuccess) return fail_hip(e, "hipOccupancyMaxActiveBlocksPerMultiprocessor");
         if (nb < 1) nb = 1;
-        if (tune.debug) fprintf(stderr, "[sdr] rx_fused<%d,%d,%d,%d,%d>: %d threads/WG, %d WG/CU, %d CUs\n", LOG2N, MI, MQ, int(FULL), int(EQ), O::kWG, nb, ctx->num_cu);
+        if (tune.debug) fprintf(stderr, "[sdr] rx_fused<%d,%d,%d,%d,%d,%d>: %d threads/WG, %d WG/CU, %d CUs\n", LOG2N, MI, MQ, int(FULL), int(EQ), int(HARDONLY), O::kWG, nb, ctx->num_cu);
         if (per_wg == 0) {
             const unsigned long long resident = static_cast<unsigned long long>(ctx->num_cu) * nb;
             per_wg = (n_groups + resident - 1) / resident;

@@ -14,7 +14,7 @@ namespace sdr {
 #define SDR_CAT(a, b) SDR_CAT_(a, b)
 
 // mod = 0: FFT only.  variant bit 0: per-subcarrier taps / weights are given (prefetching
-// instantiation); bit 1: every output optional (hard bits, bins, counters).
+// instantiation); bit 1: every output optional (hard bits, bins, counters); 4: hard bits only.
 int SDR_CAT(rx_fused_dispatch_, SDR_LOG2N)(sdr_ctx* ctx, const RxParams& p, int mod, int variant)
 {
     constexpr int L = SDR_LOG2N;
@@ -23,6 +23,7 @@ int SDR_CAT(rx_fused_dispatch_, SDR_LOG2N)(sdr_ctx* ctx, const RxParams& p, int 
         case 0: return launch_rx_fused<L, MI, MQ, false, false>(ctx, p);       \
         case 1: return launch_rx_fused<L, MI, MQ, false, true>(ctx, p);        \
         case 2: return launch_rx_fused<L, MI, MQ, true, false>(ctx, p);        \
+        case 4: return launch_rx_fused<L, MI, MQ, false, false, true>(ctx, p); \
         default: return launch_rx_fused<L, MI, MQ, true, true>(ctx, p);        \
     }
     switch (mod) {

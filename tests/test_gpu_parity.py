@@ -269,6 +269,25 @@ def test_demod_llr_only_with_taps_or_weights(ctx, oracle, n, cp, bps, which):
     assert same(out.llr.cpu().numpy(), ref["llr"])
 
 
+@pytest.mark.parametrize("n,cp,bps", [(64, 16, 2), (128, 32, 6), (512, 128, 8), (1024, 256, 4), (1024, 256, 6), (2048, 512, 6), (4096, 1024, 8),
+                                      (8192, 2048, 4), (1024, 256, 10), (256, 64, 1)])
+def test_hard_decisions_only(ctx, oracle, n, cp, bps):
+    """The reference's own chain, ofdm::rx -> from_constl (ofdm.hpp:37-43, modulation.hpp:96-112),
+    as one launch with packed hard bits as the only output (an instantiation without LLR arithmetic)."""
+    from sdr_amd.link import noise_sigma
+    n_sym = 21 if n <= 1024 else 7
+    ebn0 = {1: 4.0, 2: 5.0, 4: 9.0, 6: 14.0, 8: 19.0, 10: 24.0}[bps]
+    rx, bits = oracle.link_generate(n, cp, bps, 31 + n, 3, n_sym, np.float32(noise_sigma(n, bps, ebn0)))
+    ref = oracle.demod(rx, n, cp, bps, want_fft=False, want_llr=False)
+    out = ctx.demod(dev(rx), n, cp, bps, want_llr=False, want_hard=True)
+    assert out.llr is None and same(out.hard.cpu().numpy(), ref["hard"])
+    assert 0 < oracle.count_bit_errors(ref["hard"], bits) < 0.2 * bits.size * 8
+    # weights cannot change a hard decision
+    w = torch.rand(n, dtype=torch.float32, device="cuda") + 0.5
+    again = ctx.demod(dev(rx), n, cp, bps, llr_weight=w, want_llr=False, want_hard=True)
+    assert torch.equal(again.hard, out.hard)
+
+
 def test_demod_outputs_are_optional(ctx, oracle):
     rx, bits = oracle.link_generate(1024, 256, 4, 3, 0, 4, 0.01)
     ref = oracle.demod(rx, 1024, 256, 4, weight=2.0)

@@ -4,7 +4,8 @@
   python tools/kbench.py --cases 1024:4 1024:6 1024:0 4096:8 --symbols 262144 --steps 10
 
 case = n_fft:bps[:eq][:hard][:cnt]   (bps 0 = FFT only / ofdm::rx batch; bps 'fft' / 'ifft' = in-place fft::fft2 / ifft2 batch; eq = per-subcarrier
-equaliser sets; hard = also packed hard bits; cnt = error counters against reference bits)
+equaliser sets; hard = also packed hard bits; cnt = error counters against reference bits; nollr = no LLR
+output, i.e. with hard: the reference's own chain ofdm::rx -> from_constl)
 Inputs are random complex noise (values do not change the instruction stream).
 """
 import argparse
@@ -54,9 +55,12 @@ def main():
             ref = torch.randint(0, 256, (n_sym * n * bps // 8,), dtype=torch.uint8, device="cuda", generator=g)
             cnt = torch.zeros(8, dtype=torch.int64, device="cuda")
             bytes_sym += n * bps // 8
+        no_llr = "nollr" in parts[2:]
+        if no_llr:
+            bytes_sym -= 4 * n * bps
         if bps:
-            out = torch.empty((n_sym, n, bps), dtype=torch.float32, device="cuda")
-            step = lambda: ctx.demod(rx, n, cp, bps, eq=eq, llr_weight=(wgt if wgt is not None else 1.5), sym_per_set=per, out_llr=out,
+            out = None if no_llr else torch.empty((n_sym, n, bps), dtype=torch.float32, device="cuda")
+            step = lambda: ctx.demod(rx, n, cp, bps, eq=eq, llr_weight=(wgt if wgt is not None else 1.5), sym_per_set=per, out_llr=out, want_llr=not no_llr,
                                      out_hard=hard, ref_hard=ref, counters=cnt)
         elif fft_only:
             buf = rx.view(-1)[: n_sym * n].view(n_sym, n)
