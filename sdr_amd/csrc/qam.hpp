@@ -101,12 +101,75 @@ __device__ inline void axis_llr(const T (&d)[1 << M], T w, T* out)
     }
 }
 
+// The full evaluation, out of line: the fast path below falls back to it on (near-)ties, NaN and
+// overflow, which random data meets about once in 10^7 points.
+template <typename T, int MI, int MQ>
+__device__ __noinline__ unsigned nearest_by_scan(T ur, T ui)
+{
+    T dx[1 << MI];
+    T dy[1 << MQ];
+    axis_distances<T, MI>(ur, dx);
+    axis_distances<T, MQ>(ui, dy);
+    return nearest_from_distances<T, MI, MQ>(dx, dy);
+}
+
+// One axis of the fast path: the slicer's level A (binary index), its squared distance and the
+// smaller of the squared distances to its two neighbours (+inf beyond the edge of the grid).
+template <typename T, int M>
+__device__ inline void axis_candidate(T v, unsigned& code, T& d_best, T& d_next)
+{
+    if constexpr (M == 0) {
+        code = 0u;
+        d_best = v * v;
+        d_next = FltMax<T>::value() * T(2);                       // +inf
+    } else {
+        constexpr int L = 1 << M;
+        T a = rint((v + T(L - 1)) * T(0.5));
+        a = a > T(0) ? a : T(0);                                  // also catches NaN
+        a = a < T(L - 1) ? a : T(L - 1);
+        const T lvl = a * T(2) - T(L - 1);
+        const T dc = v - lvl, dl = v - (lvl - T(2)), dr = v - (lvl + T(2));
+        d_best = dc * dc;
+        const T inf = FltMax<T>::value() * T(2);
+        const T left = a > T(0) ? dl * dl : inf;
+        const T right = a < T(L - 1) ? dr * dr : inf;
+        d_next = min_of<T>(left, right);
+        const unsigned b = static_cast<unsigned>(static_cast<int>(a));
+        code = b ^ (b >> 1);                                      // binary -> Gray
+    }
+}
+
+// nearest() without the scan.  The slicer proposes (A, B); the proposal is the scan's answer
+// whenever it beats, AFTER rounding, the best point that differs from it on either axis:
+//   fl(next_I + d_B) > m  and  fl(d_A + next_Q) > m,   m = fl(d_A + d_B) < max.
+// Proof sketch: the computed axis distances are monotonic in |v - level| (rounding is monotonic),
+// so every other level is at least as far as the nearer neighbour; the second inequality forces
+// d_B to be the strict minimum on Q and the first d_A on I, hence m is the scan's minimum and
+// every other point rounds to something larger: the strict '<' scan from max() returns (A, B).
+// Anything else (ties, absorbed differences, NaN, overflow) takes the scan itself.
+template <typename T, int MI, int MQ>
+__device__ inline unsigned nearest_fast(T ur, T ui)
+{
+    unsigned gi, gq;
+    T da, na, db, nb;
+    axis_candidate<T, MI>(ur, gi, da, na);
+    axis_candidate<T, MQ>(ui, gq, db, nb);
+    const T m = da + db;
+    const bool sure = (na + db > m) && (da + nb > m) && (m < FltMax<T>::value());
+    if (sure) return (gi << MQ) | gq;
+    return nearest_by_scan<T, MI, MQ>(ur, ui);
+}
+
 // Everything for one subcarrier: scaled coordinates -> LLRs (MI+MQ values) and index.
 template <typename T, int MI, int MQ, bool WANT_LLR, bool WANT_IDX>
 __device__ inline unsigned demap_point(T re, T im, T inorm, T w, T* llr)
 {
     const T ur = re * inorm;
     const T ui = im * inorm;
+    if constexpr (!WANT_LLR) {
+        // hard decision alone: no need for every distance (4-level axes gain nothing from it)
+        if constexpr (WANT_IDX && (MI > 2 || MQ > 2)) return nearest_fast<T, MI, MQ>(ur, ui);
+    }
     T dx[1 << MI];
     T dy[1 << MQ];
     axis_distances<T, MI>(ur, dx);

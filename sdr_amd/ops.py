@@ -132,9 +132,12 @@ class Context:
 
     def nearest(self, sym: torch.Tensor, mod) -> torch.Tensor:
         bps = mod_bits(mod)
-        _need(sym, torch.complex64, "sym")
+        if sym.dtype not in (torch.complex64, torch.complex128):
+            raise ValueError("nearest needs a complex tensor")
+        _need(sym, sym.dtype, "sym")
         out = torch.empty(sym.numel(), dtype=torch.int16, device=sym.device)
-        check(self.lib.sdr_nearest_c32(self._h, bps, _ptr(sym), sym.numel(), _ptr(out)))
+        fn = self.lib.sdr_nearest_c32 if sym.dtype == torch.complex64 else self.lib.sdr_nearest_c64
+        check(fn(self._h, bps, _ptr(sym), sym.numel(), _ptr(out)))
         return out
 
     def soft_demap(self, sym: torch.Tensor, mod, weight=1.0) -> torch.Tensor:

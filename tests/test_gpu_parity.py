@@ -164,6 +164,46 @@ def test_nearest_and_llr_on_boundaries_and_outliers(ctx, oracle, bps):
 
 
 @pytest.mark.parametrize("bps", [1, 2, 4, 6, 8, 10])
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_nearest_adversarial_points_bit_exact(ctx, oracle, bps, dt):
+    """Everything that can separate a slicer from the reference's scan (modulation.hpp:49-67): one
+    coordinate within a few ulps of every decision boundary and of every level while the other is
+    tiny, ordinary, huge (its square absorbs the difference), on a level, infinite or NaN; both
+    orders; float and double.  The device's scan-free path must fall back exactly when it has to."""
+    mi = (bps + 1) // 2 if bps > 1 else 1
+    levels = 1 << mi
+    inorm = np.sqrt(dt(2.0 * (levels * levels - 1) / 3.0)) if bps > 1 else dt(1.0)
+    marks = np.arange(-(levels - 1) - 3, levels + 3, dtype=np.float64)             # levels, boundaries, beyond the edge
+    near = []
+    for v in marks:
+        x = dt(v) / inorm
+        for _ in range(4):
+            near.append(x)
+            x = np.nextafter(x, dt(np.inf))
+        x = dt(v) / inorm
+        for _ in range(4):
+            x = np.nextafter(x, dt(-np.inf))
+            near.append(x)
+    near = np.array(near, dtype=dt)
+    other = np.array([0.0, 1e-30, -1e-30, 0.37, -0.91, 1.0, 3.0, 40.0, -2.5e3, 1e6, -1e9, 3e18, np.inf, -np.inf, np.nan], dtype=dt)
+    other = np.concatenate([other, (np.arange(-(levels - 1), levels, 2, dtype=np.float64) / float(inorm)).astype(dt)])
+    a, b = np.meshgrid(near, other, indexing="ij")
+    cdt = np.complex64 if dt is np.float32 else np.complex128
+    pts = np.empty(2 * a.size, dtype=cdt)                       # assembled by parts: 1j * inf would make NaNs
+    pts.real = np.concatenate([a.ravel(), b.ravel()])
+    pts.imag = np.concatenate([b.ravel(), a.ravel()])
+    with np.errstate(all="ignore"):
+        want = oracle.nearest(bps, pts)
+    got = ctx.nearest(dev(pts), bps).cpu().numpy().astype(np.uint16)
+    assert same(got, want.astype(np.uint16))
+    # and through from_constl (whole bytes only)
+    k = (pts.size // 8) * 8
+    with np.errstate(all="ignore"):
+        want_bytes = oracle.from_constl(bps, pts[:k])
+    assert same(ctx.from_constl(dev(pts[:k]), bps).cpu().numpy(), want_bytes)
+
+
+@pytest.mark.parametrize("bps", [1, 2, 4, 6, 8, 10])
 def test_nearest_random_noise_bit_exact(ctx, oracle, bps):
     rng = np.random.default_rng(40 + bps)
     pts = rand_c(rng, 200000) * np.float32(0.8)
