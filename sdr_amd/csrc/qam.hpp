@@ -179,7 +179,11 @@ __device__ inline unsigned demap_point(T re, T im, T inorm, T w, T* llr)
         if (MQ > 0) axis_llr<T, MQ>(dy, w, llr + MI);
     }
     unsigned idx = 0;
-    if (WANT_IDX) idx = nearest_from_distances<T, MI, MQ>(dx, dy);
+    if constexpr (WANT_IDX) {
+        // even with every distance at hand the three-point test is cheaper than the scan from 8 levels up
+        if constexpr (MI > 2 || MQ > 2) idx = nearest_fast<T, MI, MQ>(ur, ui);
+        else idx = nearest_from_distances<T, MI, MQ>(dx, dy);
+    }
     return idx;
 }
 
