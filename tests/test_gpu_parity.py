@@ -610,3 +610,38 @@ def test_copy_shape_diagnostic_touches_every_output(ctx):
     ctx.copy_shape(rx, n, cp, bps, out)
     torch.cuda.synchronize()
     assert not torch.isnan(out).any()
+
+
+def test_contexts_and_pipes_release_their_memory(oracle):
+    """Create / use / destroy cycles leave device memory where it was (twiddle tables, staging,
+    counter slots, pipe slots and pinned buffers are all owned by the handle)."""
+    from sdr_amd.ops import Context
+    from sdr_amd.pipe import Pipe
+    rx, bits = oracle.link_generate(256, 64, 4, 1, 0, 8, np.float32(0.05))
+    drx, dbits = dev(rx), dev(bits)
+
+    def cycle():
+        c = Context(0)
+        cnt = torch.zeros(8, dtype=torch.int64, device="cuda")
+        c.demod(drx, 256, 64, 4, want_hard=True, want_fft=True, ref_hard=dbits, counters=cnt)
+        c.fft2_(torch.zeros(3 * 4096, dtype=torch.complex128, device="cuda").view(3, 4096))
+        c.link_ber(256, 64, 4, 1, 0, 64, 0.05, 1.0)
+        c.synchronize()
+        c.close()
+        with Pipe(0, n_fft=256, cp=64, mod=4, chunk_symbols=8, depth=3, llr_to_host=True, hard_to_host=True) as p:
+            p.acquire()[:] = rx.reshape(8, 320)
+            p.submit(8)
+            p.collect()
+            p.release()
+
+    for _ in range(3):
+        cycle()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(40):
+        cycle()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < (8 << 20), (free0, free1)
