@@ -99,8 +99,8 @@ int rx_fft_only_launch(sdr_ctx* ctx, const void* d_in, uint32_t n_fft, uint32_t 
 // ---- diagnostic: the memory system's ceiling for this kernel's traffic shape -------------------
 // Same access pattern as the fused receive kernel and no arithmetic: one wave per symbol reads
 // the symbol's n_fft samples (cyclic prefix skipped) with 16-byte loads, then writes the symbol's
-// n_fft * bps floats with lane-contiguous 16-byte non-temporal stores; two consecutive symbols
-// per workgroup; the same XCD-aware workgroup order.  bench.py reports its rate beside the
+// n_fft * bps floats with lane-contiguous 16-byte non-temporal stores; one symbol per
+// workgroup; the same XCD-aware workgroup order.  bench.py reports its rate beside the
 // kernel's, so that "fraction of the HBM peak" can be read against what a pure copy of this
 // shape reaches on the same box.
 namespace {
@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(64) copy_shape_kernel(const float4* __restrict
     const unsigned lane = threadIdx.x;
     const unsigned in_vec = n_fft / 2;                    // float4 = two samples
     const unsigned out_vec = n_fft * bps / 4;             // float4 = four LLRs
-    for (unsigned long long sym = wg * 2; sym < wg * 2 + 2 && sym < n_sym; ++sym) {
+    for (unsigned long long sym = wg; sym < wg + 1 && sym < n_sym; ++sym) {           // one symbol per workgroup, like the kernel
         const float4* src = rx + (sym * (static_cast<unsigned long long>(n_fft) + cp) + cp) / 2;
         float acc = 0.0f;
         for (unsigned i = lane; i < in_vec; i += 64) {
@@ -139,7 +139,7 @@ int copy_shape_launch(sdr_ctx* ctx, const void* d_rx, uint32_t n_fft, uint32_t c
     if (n_fft < 64 || (n_fft & (n_fft - 1)) != 0 || cp % 2 != 0 || bps == 0 || (static_cast<uint64_t>(n_fft) * bps) % 4 != 0)
         return fail(SDR_ERR_INVALID, "copy-shape diagnostic: n_fft >= 64 power of two, even cp");
     if (!aligned(d_rx, 16) || !aligned(d_out, 16) || !d_rx || !d_out) return fail(SDR_ERR_INVALID, "copy-shape diagnostic: 16-byte aligned buffers");
-    const unsigned long long blocks = (n_sym + 1) / 2;
+    const unsigned long long blocks = n_sym;
     if (blocks == 0) return SDR_OK;
     if (blocks > 0x7FFFFFFFull) return fail(SDR_ERR_UNSUPPORTED, "batch too large for one launch");
     const RxTuning& tune = rx_tuning();

@@ -12,7 +12,7 @@ import csv
 import json
 import sys
 
-WORKLOADS = {"fft1024_16qam_1M": "rx_fused_kernel<10, 2, 2, false, false>", "fft1024_64qam_1M": "rx_fused_kernel<10, 3, 3, false, false>"}
+WORKLOADS = {"fft1024_16qam_1M": "rx_fused_kernel<10, 2, 2, false, false, false>", "fft1024_64qam_1M": "rx_fused_kernel<10, 3, 3, false, false, false>"}
 SYMBOLS = 1 << 20
 
 
