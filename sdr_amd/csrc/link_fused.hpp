@@ -405,6 +405,8 @@ int launch_tx_fused(sdr_ctx* ctx, const TxParams& p)
     using O = PlanOps<LOG2N>;
     const unsigned long long n_groups = (p.n_sym + O::kSPW - 1) / O::kSPW;
     unsigned long long per_wg = 2;
+    static const long knob = [] { const char* v = getenv("SDR_TX_GROUPS_PER_WG"); return v ? atol(v) : 0L; }();   // tuning knob
+    if (knob > 0) per_wg = static_cast<unsigned long long>(knob);
     const unsigned long long blocks = (n_groups + per_wg - 1) / per_wg;
     if (blocks > 0x7FFFFFFFull) return fail(SDR_ERR_UNSUPPORTED, "batch too large for one launch");
     TxParams q = p;
