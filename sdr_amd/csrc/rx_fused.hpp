@@ -26,6 +26,7 @@
 // held in registers.  Compile-time experiment switches kept for A/B measurements (all measured
 // neutral or worse): SDR_WPE=<n> (force waves per SIMD), SDR_PREFETCH
 // (load the next symbol before storing this one), SDR_NT_LOADS (non-temporal sample loads),
+// SDR_PLAIN_STORES (LLR stores without the non-temporal hint),
 // SDR_NO_STAGE8 / SDR_NO_STG_ALIAS (LLR staging variants).  Run-time knobs: see RxTuning.
 #pragma once
 
@@ -327,7 +328,11 @@ typedef float sdr_v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void stream_store4(float* dst, float a, float b, float c, float d)
 {
     sdr_v4f v = {a, b, c, d};
+#ifdef SDR_PLAIN_STORES
+    *reinterpret_cast<sdr_v4f*>(dst) = v;
+#else
     __builtin_nontemporal_store(v, reinterpret_cast<sdr_v4f*>(dst));
+#endif
 }
 __device__ __forceinline__ void stream_store2(float* dst, float a, float b)
 {
