@@ -279,17 +279,32 @@ int sdr_ofdm_demod_host_c32(sdr_ctx* ctx, const sdr_demod_args* host_args, size_
     const size_t bins = size_t(a.n_sym) * a.n_fft;
     const size_t rx_bytes = size_t(a.n_sym) * (size_t(a.n_fft) + a.cp) * 8;
     const size_t hard_bytes = bins * a.mod / 8;
-    DevBuf rx, eq, wgt, llr, hard, fft, ref, cnt;
-    SDR_TRY(rx.alloc(rx_bytes));
+    // one arena from the context's staging (grown on demand, kept for the next call) instead of
+    // eight hipMalloc / hipFree pairs per call
+    const size_t set_bytes = n_sets * a.n_fft;
+    auto up = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
+    const size_t o_rx = 0;
+    const size_t o_eq = o_rx + up(rx_bytes);
+    const size_t o_wgt = o_eq + (a.d_eq ? up(set_bytes * 8) : 0);
+    const size_t o_ref = o_wgt + (a.d_llr_weight ? up(set_bytes * 4) : 0);
+    const size_t o_cnt = o_ref + (a.d_ref_hard ? up(hard_bytes) : 0);
+    const size_t o_llr = o_cnt + (a.d_counters ? up(64) : 0);
+    const size_t o_hard = o_llr + (a.d_llr ? up(bins * a.mod * 4) : 0);
+    const size_t o_fft = o_hard + (a.d_hard ? up(hard_bytes) : 0);
+    const size_t total = o_fft + (a.d_fft ? up(bins * 8) : 0);
+    void* arena_v = nullptr;
+    SDR_TRY(get_staging(ctx, 3, total, &arena_v));
+    unsigned char* arena = static_cast<unsigned char*>(arena_v);
+    struct { void* p; } rx{arena + o_rx}, eq{arena + o_eq}, wgt{arena + o_wgt}, ref{arena + o_ref}, cnt{arena + o_cnt}, llr{arena + o_llr}, hard{arena + o_hard}, fft{arena + o_fft};
     SDR_HIP(hipMemcpyAsync(rx.p, a.d_rx, rx_bytes, hipMemcpyHostToDevice, ctx->stream));
     a.d_rx = rx.p;
-    if (a.d_eq) { SDR_TRY(eq.alloc(n_sets * a.n_fft * 8)); SDR_HIP(hipMemcpyAsync(eq.p, a.d_eq, n_sets * a.n_fft * 8, hipMemcpyHostToDevice, ctx->stream)); a.d_eq = eq.p; }
-    if (a.d_llr_weight) { SDR_TRY(wgt.alloc(n_sets * a.n_fft * 4)); SDR_HIP(hipMemcpyAsync(wgt.p, a.d_llr_weight, n_sets * a.n_fft * 4, hipMemcpyHostToDevice, ctx->stream)); a.d_llr_weight = static_cast<const float*>(wgt.p); }
-    if (a.d_ref_hard) { SDR_TRY(ref.alloc(hard_bytes)); SDR_HIP(hipMemcpyAsync(ref.p, a.d_ref_hard, hard_bytes, hipMemcpyHostToDevice, ctx->stream)); a.d_ref_hard = static_cast<const uint8_t*>(ref.p); }
-    if (a.d_counters) { SDR_TRY(cnt.alloc(64)); SDR_HIP(hipMemcpyAsync(cnt.p, a.d_counters, 64, hipMemcpyHostToDevice, ctx->stream)); a.d_counters = static_cast<uint64_t*>(cnt.p); }
-    if (a.d_llr) { SDR_TRY(llr.alloc(bins * a.mod * 4)); a.d_llr = static_cast<float*>(llr.p); }
-    if (a.d_hard) { SDR_TRY(hard.alloc(hard_bytes)); a.d_hard = static_cast<uint8_t*>(hard.p); }
-    if (a.d_fft) { SDR_TRY(fft.alloc(bins * 8)); a.d_fft = fft.p; }
+    if (a.d_eq) { SDR_HIP(hipMemcpyAsync(eq.p, a.d_eq, set_bytes * 8, hipMemcpyHostToDevice, ctx->stream)); a.d_eq = eq.p; }
+    if (a.d_llr_weight) { SDR_HIP(hipMemcpyAsync(wgt.p, a.d_llr_weight, set_bytes * 4, hipMemcpyHostToDevice, ctx->stream)); a.d_llr_weight = static_cast<const float*>(wgt.p); }
+    if (a.d_ref_hard) { SDR_HIP(hipMemcpyAsync(ref.p, a.d_ref_hard, hard_bytes, hipMemcpyHostToDevice, ctx->stream)); a.d_ref_hard = static_cast<const uint8_t*>(ref.p); }
+    if (a.d_counters) { SDR_HIP(hipMemcpyAsync(cnt.p, a.d_counters, 64, hipMemcpyHostToDevice, ctx->stream)); a.d_counters = static_cast<uint64_t*>(cnt.p); }
+    if (a.d_llr) a.d_llr = static_cast<float*>(llr.p);
+    if (a.d_hard) a.d_hard = static_cast<uint8_t*>(hard.p);
+    if (a.d_fft) a.d_fft = fft.p;
     SDR_TRY(sdr_ofdm_demod_c32(ctx, &a));
     if (host_args->d_llr) SDR_HIP(hipMemcpyAsync(host_args->d_llr, llr.p, bins * a.mod * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (host_args->d_hard) SDR_HIP(hipMemcpyAsync(host_args->d_hard, hard.p, hard_bytes, hipMemcpyDeviceToHost, ctx->stream));
