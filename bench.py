@@ -105,7 +105,7 @@ def time_workload(ctx, torch, dist, name, steps, warmup, world, rank, n_sym_over
         n_sym = n_sym_override
     first = rank * ((n_sym + 13) // 14) * 14      # whole frames per rank, disjoint global symbol ranges
     rx, eq, wgt, w0, per = make_inputs(ctx, torch, n_fft, cp, bps, n_sym, ebn0, with_eq, seed=2, first_symbol=first)
-    llr = torch.empty((n_sym, n_fft, bps), dtype=torch.float32, device="cuda")
+    llr = torch.zeros((n_sym, n_fft, bps), dtype=torch.float32, device="cuda")
 
     def step():
         ctx.demod(rx, n_fft, cp, bps, eq=eq, llr_weight=(wgt if wgt is not None else w0), sym_per_set=per, out_llr=llr)
@@ -164,7 +164,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="fft1024_16qam_1M", choices=sorted(WORKLOADS))
     ap.add_argument("--symbols", type=int, default=0, help="override symbols per GPU (debug)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")

@@ -252,12 +252,12 @@ struct FftTwiddles {
     // fills the LDS table (callers __syncthreads() before the first run) and the registers
     __device__ __forceinline__ void init(const float2* __restrict__ tw, float2* lds_mid, int tid, const FftAddr<LOG2N>& a)
     {
-        constexpr int LAST = O::kLast;
         static_for<(1 << P::kR[0]) - 1>([&](auto I) { constexpr int i = I; first[i] = tw[i]; });
         if constexpr (O::kMidCount > 0) {
             for (int i = tid; i < O::kMidCount; i += O::kWG) lds_mid[i] = tw[O::kMidFirst + i];
         }
         mid = lds_mid;
+        constexpr int LAST = O::kLast;
         const int jt = a.pos_last & ((1 << P::kC0[LAST]) - 1);
         static_for<P::kR[LAST]>([&](auto S) {
             constexpr int s = S;
@@ -275,8 +275,13 @@ struct FftTwiddles {
 // All stages of the network on one symbol: x enters in the first-pass register pattern and
 // leaves in the last-pass pattern (natural order bins).  Contains the workgroup barriers of the
 // exchanges; the caller barriers before the exchange region is reused.
-template <int LOG2N, bool CONJ = false>
-__device__ __forceinline__ void fft_run(float2 (&x)[PlanOps<LOG2N>::kE], unsigned char* lds_data, const FftAddr<LOG2N>& a, const FftTwiddles<LOG2N>& w)
+struct NoLateWork { __device__ __forceinline__ void operator()() const {} };
+
+// `late` runs between the two barriers of the second exchange (3-pass plans): the place where
+// kernels that are short of registers request what only the last pass and the epilogue need
+// (last-pass twiddles, equaliser taps), so that it is not live across the first two passes.
+template <int LOG2N, bool CONJ = false, typename Late = NoLateWork, int LATE_AT = 1>
+__device__ __forceinline__ void fft_run(float2 (&x)[PlanOps<LOG2N>::kE], unsigned char* lds_data, const FftAddr<LOG2N>& a, const FftTwiddles<LOG2N>& w, Late&& late = Late{})
 {
     using O = PlanOps<LOG2N>;
     using P = typename O::P;
@@ -291,6 +296,7 @@ __device__ __forceinline__ void fft_run(float2 (&x)[PlanOps<LOG2N>::kE], unsigne
         });
     });
     static_for<E>([&](auto M) { constexpr int m = M; *reinterpret_cast<float2*>(lds_data + a.wr0 + O::reg_addr(0, 0, m)) = x[m]; });
+    if constexpr (LATE_AT == 0) late();
     __syncthreads();
     static_for<E>([&](auto M) { constexpr int m = M; x[m] = *reinterpret_cast<const float2*>(lds_data + a.rd0 + O::reg_addr(0, 1, m)); });
     if constexpr (O::kPasses == 3) {
@@ -304,6 +310,7 @@ __device__ __forceinline__ void fft_run(float2 (&x)[PlanOps<LOG2N>::kE], unsigne
             });
         });
         __syncthreads();   // all reads of exchange 0 done before the region is rewritten
+        if constexpr (LATE_AT == 1) late();
         static_for<E>([&](auto M) { constexpr int m = M; *reinterpret_cast<float2*>(lds_data + a.wr1 + O::reg_addr(1, 1, m)) = x[m]; });
         __syncthreads();
         static_for<E>([&](auto M) { constexpr int m = M; x[m] = *reinterpret_cast<const float2*>(lds_data + a.rd1 + O::reg_addr(1, 2, m)); });
@@ -364,61 +371,110 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
     return v;
 }
 
-#ifdef SDR_WPE
-#define SDR_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(SDR_WPE, SDR_WPE)))
-#else
-// The tap-prefetching variant must not drift above the register budget of the plain one: left
-// alone the scheduler spends 256+ registers on it and the CU drops to one wave per SIMD.
+#ifndef SDR_LATE_AT
+#define SDR_LATE_AT 0
+#endif
+#ifndef SDR_LATE_TAPS
+#define SDR_LATE_TAPS 0
+#endif
 #ifndef SDR_EQ_WPE
 #define SDR_EQ_WPE 2
 #endif
-// N = 8192 (E = 32): FULL variants are held to one workgroup per CU by LDS and the tap-holding ones
-// would spill (measured 49 -> 33 %); the others fit two if
-// they stay within 256 registers.
-#define SDR_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(LOG2N >= 13 ? ((FULL || EQ || HARDONLY) ? 1 : 2) : ((EQ || FULL) ? SDR_EQ_WPE : 1))))
+#ifndef SDR_ALIAS_FROM
+#define SDR_ALIAS_FROM 13
 #endif
 
+// Compile-time shape of one instantiation: LDS layout, control structure and the bounds on the
+// waves per SIMD handed to the compiler.
+template <int LOG2N, int MI, int MQ, bool FULL, bool EQ, bool HARDONLY>
+struct RxShape {
+    using O = PlanOps<LOG2N>;
+    static constexpr int N = O::kN, SPW = O::kSPW;
+    static constexpr int BPS = MI + MQ;
+    static constexpr bool DEMAP = BPS > 0;
+    static_assert(!(HARDONLY && (FULL || EQ || !DEMAP)), "HARDONLY is a variant of its own");
+    static constexpr int SYM_BYTES = O::max_sym_bytes();
+    static constexpr int DATA_BYTES = SYM_BYTES * SPW;
+    static constexpr int TW_BYTES = O::kMidCount * 8;
+    using idx_t = std::conditional_t<(BPS > 8), uint16_t, uint8_t>;      // one hard decision
+    static constexpr bool HARD_PATH = (FULL || HARDONLY) && DEMAP;       // hard decisions pass through LDS and are packed
+    static constexpr int IDX_BYTES = HARD_PATH ? N * SPW * static_cast<int>(sizeof(idx_t)) : 0;
+    static constexpr int REF_SYM_BYTES = N * (DEMAP ? BPS : 8) / 8;      // reference bits of one symbol
+    static constexpr int REF_BYTES = (FULL && DEMAP) ? REF_SYM_BYTES * SPW : 0;
+    static constexpr int CHUNK = O::kGroupOut * BPS;                     // LLR floats per lane per output block
+    static constexpr bool STAGE = DEMAP && !HARDONLY && SPW == 1 && stage_wanted(CHUNK);
+    static constexpr int STG_STRIDE = stage_stride_bytes(CHUNK);
+    static constexpr int STG_WAVE_BYTES = STAGE ? 64 * STG_STRIDE : 0;
+    static constexpr int STG_BYTES = STG_WAVE_BYTES * (O::kWG / 64);
+    // The staging strips reuse the exchange region when they fit: it is dead between the last
+    // exchange read and the next symbol's first exchange write.  Multi-wave workgroups need a
+    // barrier for it, which costs more than it gains at N = 2048/4096 (measured); at N = 8192 it is
+    // the difference between one and two workgroups per CU.
+#ifdef SDR_NO_STG_ALIAS
+    static constexpr bool STG_ALIAS = false;
+#else
+    static constexpr bool STG_ALIAS = STAGE && STG_BYTES <= DATA_BYTES && (O::kWG == 64 || LOG2N >= SDR_ALIAS_FROM);
+#endif
+    static constexpr int STG_OFF = STG_ALIAS ? 0 : (DATA_BYTES + TW_BYTES + IDX_BYTES + REF_BYTES + 15) & ~15;
+    static constexpr int LDS_BYTES = (STG_ALIAS ? DATA_BYTES + TW_BYTES + IDX_BYTES + REF_BYTES : STG_OFF + STG_BYTES) + 16;
+
+    // N = 2048 / 4096 with taps: requested per symbol between the barriers of the second exchange
+    // (they land during the last pass) instead of being held across a run of symbols -- 48 fewer
+    // live registers, three waves per SIMD instead of two.
+    static constexpr bool LATE_TAPS = SDR_LATE_TAPS && EQ && DEMAP && O::kPasses == 3 && LOG2N >= 11 && LOG2N <= 12;
+    // Instantiations that take a run of symbol groups per workgroup: counting ones (every workgroup
+    // ends with atomics) and tap-holding ones (taps reloaded once per run).  The others take exactly
+    // one group and are straight-line code: nothing is hoisted out of a loop into registers.
+#ifdef SDR_ALWAYS_LOOP
+    static constexpr bool LOOP = true;
+#else
+    static constexpr bool LOOP = FULL || (EQ && !LATE_TAPS);
+#endif
+
+    // Waves per SIMD.  Lower bound = register budget: the tap-holding and FULL variants must not
+    // drift to 256+ registers (one wave per SIMD); at N = 8192 (E = 32) FULL variants are held to
+    // one workgroup per CU by LDS and tap-holding ones would spill at two (measured 49 -> 33 %).
+    // Upper bound = what LDS lets a CU hold, spread evenly over its four SIMDs: when the registers
+    // allow more per SIMD than that, the dispatcher fills the SIMDs unevenly and a two- or four-wave
+    // workgroup loses 5-8 points (N = 2048 / 64-QAM at 114 registers: 65 %; the same code padded to
+    // 168 registers, i.e. three waves per SIMD: 73 %).  The compiler pads the allocation for it.
+    static constexpr int WAVES_PER_WG = O::kWG / 64;
+    static constexpr int LDS_WAVES = (160 * 1024 / ((LDS_BYTES + 511) & ~511)) * WAVES_PER_WG;
+#ifdef SDR_WPE
+    static constexpr int MIN_WAVES = SDR_WPE, MAX_WAVES = SDR_WPE;
+#else
+    static constexpr int MIN_WAVES = LOG2N >= 13 ? ((FULL || EQ || HARDONLY) ? 1 : 2) : FULL ? SDR_EQ_WPE : EQ ? (LATE_TAPS ? 3 : SDR_EQ_WPE) : 1;
+    static constexpr int even_share() { const int w = (LDS_WAVES + 3) / 4; return w < 1 ? 1 : w > 8 ? 8 : w; }
+#ifdef SDR_NO_MAX_WAVES
+    static constexpr int MAX_WAVES = 8;
+#else
+    static constexpr int MAX_WAVES = even_share() < MIN_WAVES ? MIN_WAVES : even_share();
+#endif
+#endif
+};
+
 // MI + MQ == 0: FFT only (bins to p.fft).  FULL: every output optional at run time.
-// EQ: per-subcarrier taps / LLR weights may be given; they live in registers across the symbols of
-// a set (costs registers, hence a separate instantiation).
+// EQ: per-subcarrier taps / LLR weights may be given (held in registers across the symbols of a
+// set, or requested per symbol: RxShape::LATE_TAPS; costs registers, hence a separate instantiation).
 // HARDONLY: packed hard decisions are the only output (the reference's own chain ofdm::rx ->
 // from_constl, lib/inc/ofdm.hpp:37-43 + modulation.hpp:96-112): no LLR arithmetic at all.
 template <int LOG2N, int MI, int MQ, bool FULL, bool EQ, bool HARDONLY = false>
-__global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) SDR_WAVES_ATTR rx_fused_kernel(const RxParams p)
+__global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
+    __attribute__((amdgpu_waves_per_eu(RxShape<LOG2N, MI, MQ, FULL, EQ, HARDONLY>::MIN_WAVES, RxShape<LOG2N, MI, MQ, FULL, EQ, HARDONLY>::MAX_WAVES)))
+    rx_fused_kernel(const RxParams p)
 {
     using O = PlanOps<LOG2N>;
     using P = typename O::P;
+    using S = RxShape<LOG2N, MI, MQ, FULL, EQ, HARDONLY>;
+    using idx_t = typename S::idx_t;
     constexpr int N = O::kN, E = O::kE, TPS = O::kTPS, SPW = O::kSPW, LAST = O::kLast;
-    constexpr int BPS = MI + MQ;
-    constexpr bool DEMAP = BPS > 0;
-    constexpr int SYM_BYTES = O::max_sym_bytes();
-    constexpr int DATA_BYTES = SYM_BYTES * SPW;
-    constexpr int TW_BYTES = O::kMidCount * 8;
-    using idx_t = std::conditional_t<(BPS > 8), uint16_t, uint8_t>;      // one hard decision
-    static_assert(!(HARDONLY && (FULL || EQ || !DEMAP)), "HARDONLY is a variant of its own");
-    constexpr bool HARD_PATH = (FULL || HARDONLY) && DEMAP;          // hard decisions pass through LDS and are packed
-    constexpr int IDX_BYTES = HARD_PATH ? N * SPW * static_cast<int>(sizeof(idx_t)) : 0;
-    constexpr int REF_SYM_BYTES = N * (DEMAP ? BPS : 8) / 8;      // reference bits of one symbol
-    constexpr int REF_BYTES = (FULL && DEMAP) ? REF_SYM_BYTES * SPW : 0;
-    constexpr int CHUNK = O::kGroupOut * BPS;                      // LLR floats per lane per output block
-    constexpr bool STAGE = DEMAP && !HARDONLY && SPW == 1 && stage_wanted(CHUNK);
-    constexpr int STG_STRIDE = stage_stride_bytes(CHUNK);
-    constexpr int STG_WAVE_BYTES = STAGE ? 64 * STG_STRIDE : 0;
-    constexpr int STG_BYTES = STG_WAVE_BYTES * (O::kWG / 64);
-    // The staging strips reuse the exchange region when they fit: it is dead between the last
-    // exchange read and the next symbol's first exchange write.  LDS, not registers, bounds the
-    // resident waves of this kernel (20 KB per one-wave workgroup = 7 waves per CU at N = 1024;
-    // 12-16 with the alias -- which measured neutral: the kernel sits at the memory system's ceiling).
-#ifdef SDR_NO_STG_ALIAS
-    constexpr bool STG_ALIAS = false;
-#else
-    // multi-wave workgroups need a barrier for it, which costs more than it gains at N = 2048/4096
-    // (measured); at N = 8192 it is the difference between one and two workgroups per CU
-    constexpr bool STG_ALIAS = STAGE && STG_BYTES <= DATA_BYTES && (O::kWG == 64 || LOG2N >= 13);
-#endif
-    constexpr int STG_OFF = STG_ALIAS ? 0 : (DATA_BYTES + TW_BYTES + IDX_BYTES + REF_BYTES + 15) & ~15;
-    constexpr int LDS_BYTES = STG_ALIAS ? DATA_BYTES + TW_BYTES + IDX_BYTES + REF_BYTES : STG_OFF + STG_BYTES;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES + 16];
+    constexpr int BPS = S::BPS;
+    constexpr bool DEMAP = S::DEMAP, HARD_PATH = S::HARD_PATH, STAGE = S::STAGE, STG_ALIAS = S::STG_ALIAS;
+    constexpr int SYM_BYTES = S::SYM_BYTES, DATA_BYTES = S::DATA_BYTES, TW_BYTES = S::TW_BYTES, IDX_BYTES = S::IDX_BYTES;
+    constexpr int REF_SYM_BYTES = S::REF_SYM_BYTES, CHUNK = S::CHUNK, STG_STRIDE = S::STG_STRIDE;
+    constexpr int STG_WAVE_BYTES = S::STG_WAVE_BYTES, STG_OFF = S::STG_OFF, LDS_BYTES = S::LDS_BYTES;
+    constexpr bool LATE_TAPS = S::LATE_TAPS, LOOP = S::LOOP;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
     unsigned char* lds_data = lds;
     [[maybe_unused]] idx_t* lds_idx = reinterpret_cast<idx_t*>(lds + DATA_BYTES + TW_BYTES);
     [[maybe_unused]] unsigned char* lds_ref = lds + DATA_BYTES + TW_BYTES + IDX_BYTES;
@@ -490,7 +546,9 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) SDR_WAVES_ATTR rx_fused_k
     float2 xn[E];
     if (grp_begin < grp_end) load_symbol(grp_begin, xn);
 #endif
-    for (unsigned long long grp = grp_begin; grp < grp_end; ++grp) {
+    if (grp_begin >= grp_end) return;      // uniform over the workgroup
+    unsigned long long grp = grp_begin;
+    do {
         unsigned long long sym = grp * SPW + slot;
         const bool active = sym < p.n_sym;
         if (!active) sym = p.n_sym - 1;
@@ -506,27 +564,37 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) SDR_WAVES_ATTR rx_fused_k
         // samples) whose values are never used.
         [[maybe_unused]] size_t tap_set = 0;
         if constexpr (EQ && DEMAP) tap_set = p.sym_per_set ? static_cast<size_t>(sym / p.sym_per_set) : 0;
-        if constexpr (PREFETCH_TAPS) {
+        auto load_taps = [&]() {
+            if constexpr (PREFETCH_TAPS) {
+            constexpr int GO_ = O::kGroupOut;
+            const float2* dummy = p.rx + static_cast<size_t>(sym) * in_stride;      // >= N readable float2
+#ifdef SDR_EQ_SET0      // experiment: every symbol reads the taps of set 0 (cache-resident)
+            const float2* eq_src = p.eq ? p.eq : dummy;
+            const float* wgt_src = p.wgt ? p.wgt : reinterpret_cast<const float*>(dummy);
+#else
+            const float2* eq_src = p.eq ? p.eq + tap_set * N : dummy;
+            const float* wgt_src = p.wgt ? p.wgt + tap_set * N : reinterpret_cast<const float*>(dummy);
+#endif
+            static_for<E / GO_>([&](auto Hh) {
+                constexpr int h = Hh;
+                const int k = O::reg_pos(LAST, h * GO_) | pos_last;
+                if constexpr (GO_ == 2) {
+                    const float4 v = *reinterpret_cast<const float4*>(eq_src + k);
+                    eqv[h * 2] = make_float2(v.x, v.y);
+                    eqv[h * 2 + 1] = make_float2(v.z, v.w);
+                    const float2 u = *reinterpret_cast<const float2*>(wgt_src + k);
+                    wv[h * 2] = u.x;
+                    wv[h * 2 + 1] = u.y;
+                } else {
+                    static_for<GO_>([&](auto G) { constexpr int g = G; eqv[h * GO_ + g] = eq_src[k + g]; wv[h * GO_ + g] = wgt_src[k + g]; });
+                }
+            });
+            }
+        };
+        if constexpr (PREFETCH_TAPS && !LATE_TAPS) {
             if (tap_set != held_set) {
                 held_set = tap_set;
-                constexpr int GO_ = O::kGroupOut;
-                const float2* dummy = p.rx + static_cast<size_t>(sym) * in_stride;      // >= N readable float2
-                const float2* eq_src = p.eq ? p.eq + tap_set * N : dummy;
-                const float* wgt_src = p.wgt ? p.wgt + tap_set * N : reinterpret_cast<const float*>(dummy);
-                static_for<E / GO_>([&](auto Hh) {
-                    constexpr int h = Hh;
-                    const int k = O::reg_pos(LAST, h * GO_) | pos_last;
-                    if constexpr (GO_ == 2) {
-                        const float4 v = *reinterpret_cast<const float4*>(eq_src + k);
-                        eqv[h * 2] = make_float2(v.x, v.y);
-                        eqv[h * 2 + 1] = make_float2(v.z, v.w);
-                        const float2 u = *reinterpret_cast<const float2*>(wgt_src + k);
-                        wv[h * 2] = u.x;
-                        wv[h * 2 + 1] = u.y;
-                    } else {
-                        static_for<GO_>([&](auto G) { constexpr int g = G; eqv[h * GO_ + g] = eq_src[k + g]; wv[h * GO_ + g] = wgt_src[k + g]; });
-                    }
-                });
+                load_taps();
             }
         }
 
@@ -563,7 +631,12 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) SDR_WAVES_ATTR rx_fused_k
             });
         }
 
-        fft_run<LOG2N>(x, lds_data, addr, tw);
+        if constexpr (LATE_TAPS) {
+            auto late = [&]() { load_taps(); };
+            fft_run<LOG2N, false, decltype(late), SDR_LATE_AT>(x, lds_data, addr, tw, std::move(late));
+        } else {
+            fft_run<LOG2N>(x, lds_data, addr, tw);
+        }
 
         if constexpr (STG_ALIAS && O::kWG > 64) __syncthreads();   // every wave is past its last exchange read
 
@@ -698,8 +771,8 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) SDR_WAVES_ATTR rx_fused_k
                 }
             }
         }
-        __syncthreads();   // LDS regions are reused by the next symbol group
-    }
+        if constexpr (LOOP) __syncthreads();   // LDS regions are reused by the next symbol group
+    } while (LOOP && ++grp < grp_end);
 
     if constexpr (FULL && DEMAP) {
         if (p.counters) {
@@ -755,8 +828,10 @@ int launch_rx_fused(sdr_ctx* ctx, const RxParams& p)
     // twiddle set-up is cheap, the finer grain balances better), and far better than a resident
     // grid striding over the batch.  Two exceptions: the tap-holding variants reload their taps
     // once per run (two groups: 64 % against 57 %), and counting ends every workgroup with atomics.
+    constexpr bool LOOP = RxShape<LOG2N, MI, MQ, FULL, EQ, HARDONLY>::LOOP;
     unsigned long long per_wg = p.counters ? 8 : EQ ? 2 : 1;
     if (tune.groups_per_wg >= 0) per_wg = static_cast<unsigned long long>(tune.groups_per_wg);
+    if (!LOOP) per_wg = 1;
     if (per_wg == 0 || tune.debug) {
         int nb = 0;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, O::kWG, static_cast<size_t>(tune.lds_pad > 0 ? tune.lds_pad : 0));

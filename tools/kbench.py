@@ -20,8 +20,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", nargs="+", default=["1024:4", "1024:6"])
     ap.add_argument("--symbols", type=int, default=0, help="symbols per case (default: ~8 GiB of input+output)")
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=8, help="fresh buffers run slow for their first 2-3 launches (first touch)")
     ap.add_argument("--repeat", type=int, default=1, help="time every case this many times (interleaved) and report the median")
     args = ap.parse_args()
     import torch
