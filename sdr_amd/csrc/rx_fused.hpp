@@ -374,6 +374,9 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 #ifndef SDR_LATE_AT
 #define SDR_LATE_AT 0
 #endif
+#ifndef SDR_LATE_TAPS_FULL
+#define SDR_LATE_TAPS_FULL 0
+#endif
 #ifndef SDR_LATE_TAPS
 #define SDR_LATE_TAPS 0
 #endif
@@ -421,14 +424,16 @@ struct RxShape {
     // N = 2048 / 4096 with taps: requested per symbol between the barriers of the second exchange
     // (they land during the last pass) instead of being held across a run of symbols -- 48 fewer
     // live registers, three waves per SIMD instead of two.
-    static constexpr bool LATE_TAPS = SDR_LATE_TAPS && EQ && DEMAP && O::kPasses == 3 && LOG2N >= 11 && LOG2N <= 12;
-    // Instantiations that take a run of symbol groups per workgroup: counting ones (every workgroup
-    // ends with atomics) and tap-holding ones (taps reloaded once per run).  The others take exactly
-    // one group and are straight-line code: nothing is hoisted out of a loop into registers.
+    static constexpr bool LATE_TAPS = EQ && DEMAP && O::kPasses == 3 && (FULL ? SDR_LATE_TAPS_FULL : (SDR_LATE_TAPS && LOG2N >= 11 && LOG2N <= 12));
+    // Only the tap-holding instantiations take a run of symbol groups per workgroup (taps reloaded
+    // once per run).  The others take exactly one group and are straight-line code: nothing is
+    // hoisted out of a loop into registers (N = 1024 LLR variant: 136 -> 104-119 registers; hard bits
+    // beside LLRs: 63 -> 68 %; N = 8192: 56 -> 71 %).  Counting variants then end every symbol with
+    // four atomics per wave on the 1024 counter slots, which measured no slower than runs of eight.
 #ifdef SDR_ALWAYS_LOOP
     static constexpr bool LOOP = true;
 #else
-    static constexpr bool LOOP = FULL || (EQ && !LATE_TAPS);
+    static constexpr bool LOOP = EQ && !LATE_TAPS;
 #endif
 
     // Waves per SIMD.  Lower bound = register budget: the tap-holding and FULL variants must not
