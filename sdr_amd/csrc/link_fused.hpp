@@ -102,11 +102,49 @@ __device__ __forceinline__ void for_each_tx_index(unsigned long long seed, unsig
     });
 }
 
+#ifndef SDR_TX_STRAIGHT
+#define SDR_TX_STRAIGHT 1
+#endif
+// Compile-time shape of one transmit instantiation (see RxShape in rx_fused.hpp for the reasoning).
+#ifndef SDR_TX_DIRECT
+#define SDR_TX_DIRECT 1
+#endif
+template <int LOG2N, int MI, int MQ, bool SRC_GLOBAL, bool NOISE>
+struct TxShape {
+    using O = PlanOps<LOG2N>;
+    static constexpr int N = O::kN, SPW = O::kSPW;
+    static constexpr int DATA_BYTES = O::max_sym_bytes() * SPW;
+    static constexpr int TW_BYTES = O::kMidCount * 8;
+    using idx_t = std::conditional_t<(MI + MQ > 8), uint16_t, uint8_t>;
+    static constexpr int IDX_BYTES = SRC_GLOBAL ? 0 : N * SPW * static_cast<int>(sizeof(idx_t));
+    static constexpr int TIME_OFF = (DATA_BYTES + TW_BYTES + IDX_BYTES + 15) & ~15;
+    // the plain batched ofdm::tx stores straight from the registers of the last pass (prefix = the
+    // tail stored a second time); the generator assembles the symbol in LDS (rolled noise loops)
+    static constexpr bool DIRECT = SDR_TX_DIRECT && SRC_GLOBAL && !NOISE && SPW == 1;      // several symbols per wave: the LDS-assembled rows store better (N = 64: 5.2e9 against 4.5e9 symbols/s)
+    static constexpr int LDS_BYTES = TIME_OFF + (DIRECT ? 0 : N * 8 * SPW) + 16;
+    // the plain batched ofdm::tx takes one symbol group per workgroup as straight-line code; the
+    // generator (Philox + Box-Muller, ALU bound) keeps its runs of two
+    static constexpr bool LOOP = !(SDR_TX_STRAIGHT && SRC_GLOBAL);
+    // two waves per SIMD where LDS allows two workgroups (left alone the compiler takes 256 + a few
+    // registers), and never more per SIMD than an even spread of what LDS lets the CU hold
+    static constexpr int WAVES_PER_WG = O::kWG / 64;
+    static constexpr int LDS_WAVES = (160 * 1024 / ((LDS_BYTES + 511) & ~511)) * WAVES_PER_WG;
+    static constexpr int MIN_WAVES = LOG2N <= 12 ? 2 : 1;
+    static constexpr int even_share() { const int w = (LDS_WAVES + 3) / 4; return w < 1 ? 1 : w > 8 ? 8 : w; }
+#ifdef SDR_NO_MAX_WAVES
+    static constexpr int MAX_WAVES = 8;
+#else
+    static constexpr int MAX_WAVES = even_share() < MIN_WAVES ? MIN_WAVES : even_share();
+#endif
+};
+
 // MI + MQ == 0 with SRC_GLOBAL: plain batched ofdm::tx.  SRC_GLOBAL = false: Philox generator.
 template <int LOG2N, int MI, int MQ, bool SRC_GLOBAL, bool NOISE>
-// two waves per SIMD where LDS allows two workgroups: left alone the compiler takes 256 + a few registers
-__global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) __attribute__((amdgpu_waves_per_eu(LOG2N <= 12 ? 2 : 1))) tx_fused_kernel(const TxParams p)
+__global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
+    __attribute__((amdgpu_waves_per_eu(TxShape<LOG2N, MI, MQ, SRC_GLOBAL, NOISE>::MIN_WAVES, TxShape<LOG2N, MI, MQ, SRC_GLOBAL, NOISE>::MAX_WAVES)))
+    tx_fused_kernel(const TxParams p)
 {
+    constexpr bool LOOP = TxShape<LOG2N, MI, MQ, SRC_GLOBAL, NOISE>::LOOP;
     using O = PlanOps<LOG2N>;
     using P = typename O::P;
     using A = FftAddr<LOG2N>;
@@ -118,7 +156,10 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) __attribute__((amdgpu_wav
     using idx_t = std::conditional_t<(MI + MQ > 8), uint16_t, uint8_t>;
     constexpr int IDX_BYTES = SRC_GLOBAL ? 0 : N * SPW * static_cast<int>(sizeof(idx_t));
     constexpr int TIME_OFF = (DATA_BYTES + TW_BYTES + IDX_BYTES + 15) & ~15;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[TIME_OFF + N * 8 * SPW + 16];
+    using S = TxShape<LOG2N, MI, MQ, SRC_GLOBAL, NOISE>;
+    static_assert(S::TIME_OFF == TIME_OFF, "TxShape mirrors the kernel's LDS layout");
+    constexpr bool DIRECT = S::DIRECT;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[S::LDS_BYTES];
     idx_t* lds_idx = reinterpret_cast<idx_t*>(lds + DATA_BYTES + TW_BYTES);
     float2* lds_time = reinterpret_cast<float2*>(lds + TIME_OFF) + slot_of(threadIdx.x, TPS) * N;   // this symbol's time-domain samples
 
@@ -137,7 +178,9 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) __attribute__((amdgpu_wav
     const size_t out_stride = static_cast<size_t>(N) + p.cp;
     const unsigned long long first_set = p.sym_per_set ? p.first_symbol / p.sym_per_set : 0;
 
-    for (unsigned long long grp = grp_begin; grp < grp_end; ++grp) {
+    if (grp_begin >= grp_end) return;      // uniform over the workgroup
+    unsigned long long grp = grp_begin;
+    do {
         unsigned long long sym = grp * SPW + slot;
         const bool active = sym < p.n_sym;
         if (!active) sym = p.n_sym - 1;
@@ -191,6 +234,35 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) __attribute__((amdgpu_wav
         // The symbol is assembled in LDS in natural order, so that the noise is a rolled loop
         // (unrolled, sixteen Philox + Box-Muller chains per thread took 250 + 160 registers) and
         // the stores are contiguous over the lanes.
+        if constexpr (DIRECT) {
+            constexpr int GO = O::kGroupOut;
+            const int tail = N - cp;                                 // samples from here on are the prefix too
+            if (active) {
+                static_for<E / GO>([&](auto Hh) {
+                    constexpr int h = Hh;
+                    const int k = A::out_reg(h * GO) | addr.pos_last;
+                    if constexpr (GO == 2) {
+                        const float4 v = make_float4(x[h * 2].x * INV_LEN, x[h * 2].y * INV_LEN, x[h * 2 + 1].x * INV_LEN, x[h * 2 + 1].y * INV_LEN);
+                        if (p.vec16) {
+                            *reinterpret_cast<float4*>(dst + cp + k) = v;
+                            if (k >= tail) *reinterpret_cast<float4*>(dst + (k - tail)) = v;
+                        } else {
+                            dst[cp + k] = make_float2(v.x, v.y);
+                            dst[cp + k + 1] = make_float2(v.z, v.w);
+                            if (k >= tail) dst[k - tail] = make_float2(v.x, v.y);
+                            if (k + 1 >= tail) dst[k + 1 - tail] = make_float2(v.z, v.w);
+                        }
+                    } else {
+                        static_for<GO>([&](auto G) {
+                            constexpr int g = G;
+                            const float2 v = make_float2(x[h * GO + g].x * INV_LEN, x[h * GO + g].y * INV_LEN);
+                            dst[cp + k + g] = v;
+                            if (k + g >= tail) dst[k + g - tail] = v;
+                        });
+                    }
+                });
+            }
+        } else {
         static_for<E>([&](auto M) {
             constexpr int m = M;
             lds_time[A::out_reg(m) | addr.pos_last] = make_float2(x[m].x * INV_LEN, x[m].y * INV_LEN);
@@ -234,6 +306,7 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) __attribute__((amdgpu_wav
                 for (int i = 0; i < E; ++i) dst[cp + i * TPS + t] = lds_time[i * TPS + t];
             }
         }
+        }      // !DIRECT
         if constexpr (!SRC_GLOBAL) {
             if (p.tx_bits) {
                 __syncthreads();
@@ -255,8 +328,8 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) __attribute__((amdgpu_wav
                 }
             }
         }
-        __syncthreads();
-    }
+        if constexpr (LOOP) __syncthreads();
+    } while (LOOP && ++grp < grp_end);
 }
 
 #ifdef SDR_MC_WPE
@@ -407,6 +480,7 @@ int launch_tx_fused(sdr_ctx* ctx, const TxParams& p)
     unsigned long long per_wg = 2;
     static const long knob = [] { const char* v = getenv("SDR_TX_GROUPS_PER_WG"); return v ? atol(v) : 0L; }();   // tuning knob
     if (knob > 0) per_wg = static_cast<unsigned long long>(knob);
+    if (!TxShape<LOG2N, MI, MQ, SRC_GLOBAL, NOISE>::LOOP) per_wg = 1;
     const unsigned long long blocks = (n_groups + per_wg - 1) / per_wg;
     if (blocks > 0x7FFFFFFFull) return fail(SDR_ERR_UNSUPPORTED, "batch too large for one launch");
     TxParams q = p;

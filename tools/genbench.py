@@ -11,7 +11,7 @@ def main():
     import torch
     from sdr_amd.ops import Context
     ctx = Context(0)
-    for n, bps in [(1024, 4), (1024, 6), (2048, 6), (4096, 8), (64, 2)]:
+    for n, bps in [(1024, 4), (1024, 6), (2048, 6), (4096, 8), (8192, 6), (512, 4), (64, 2)]:
         cp = n // 4
         n_sym = min(1 << 18, (4 << 30) // ((n + cp) * 8))
         out = torch.empty((n_sym, n + cp), dtype=torch.complex64, device="cuda")
@@ -22,16 +22,16 @@ def main():
             "ofdm_tx": lambda: ctx.ofdm_tx(freq, n, cp),
         }
         for name, fn in cases.items():
-            for _ in range(2):
+            for _ in range(6):
                 fn()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(5):
+            for _ in range(12):
                 fn()
             e1.record()
             torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / 5
+            ms = e0.elapsed_time(e1) / 12
             wr = n_sym * (n + cp) * 8 / ms / 1e6
             print(f"N={n:5d} bps={bps} {name:>15s}: {n_sym / ms / 1e3:8.2f} Msym/s  written {wr:7.1f} GB/s", flush=True)
     ctx.close()
