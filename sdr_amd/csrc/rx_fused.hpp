@@ -405,7 +405,11 @@ struct RxShape {
     static constexpr int REF_SYM_BYTES = N * (DEMAP ? BPS : 8) / 8;      // reference bits of one symbol
     static constexpr int REF_BYTES = (FULL && DEMAP) ? REF_SYM_BYTES * SPW : 0;
     static constexpr int CHUNK = O::kGroupOut * BPS;                     // LLR floats per lane per output block
+#ifdef SDR_NO_SMALL_STAGE
     static constexpr bool STAGE = DEMAP && !HARDONLY && SPW == 1 && stage_wanted(CHUNK);
+#else
+    static constexpr bool STAGE = DEMAP && !HARDONLY && stage_wanted(CHUNK);
+#endif
     static constexpr int STG_STRIDE = stage_stride_bytes(CHUNK);
     static constexpr int STG_WAVE_BYTES = STAGE ? 64 * STG_STRIDE : 0;
     static constexpr int STG_BYTES = STG_WAVE_BYTES * (O::kWG / 64);
@@ -688,7 +692,10 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
                     idx[g] = demap_point<float, MI, MQ, !HARDONLY, HARD_PATH>(y.x, y.y, p.inorm, w, l + g * BPS);
                 });
                 if constexpr (STAGE) {
-                    if (p.llr && active) {
+                    // SPW == 1: the wave's block is one contiguous span of the symbol.  SPW > 1 (one
+                    // wave = SPW symbols): one contiguous run of TPS * CHUNK floats per symbol, so the
+                    // copy is wave-wide and checks the destination symbol, not the lane's own.
+                    if (p.llr && (SPW > 1 || active)) {
                         constexpr int VW = (CHUNK % 4 == 0) ? 4 : 2;            // floats per vector
                         constexpr int VPL = CHUNK / VW;                          // vectors per lane
                         const int lane = tid & 63;
@@ -701,12 +708,26 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
                             constexpr int i = I;
                             const int v = i * 64 + lane;
                             const float* src = stg + (v / VPL) * (STG_STRIDE / 4) + (v % VPL) * VW;
-                            if constexpr (VW == 4) {
-                                const float4 q4 = *reinterpret_cast<const float4*>(src);
-                                stream_store4(gbase + v * 4, q4.x, q4.y, q4.z, q4.w);
+                            float* dst;
+                            bool ok = true;
+                            if constexpr (SPW == 1) {
+                                dst = gbase + v * VW;
                             } else {
-                                const float2 q2 = *reinterpret_cast<const float2*>(src);
-                                stream_store2(gbase + v * 2, q2.x, q2.y);
+                                constexpr int RUN = TPS * CHUNK;                 // floats per symbol in this block
+                                static_assert(RUN % VW == 0, "vectors do not straddle symbols");
+                                const int s_ = (v * VW) / RUN, off = (v * VW) % RUN;
+                                const unsigned long long dsym = grp * SPW + s_;
+                                ok = dsym < p.n_sym;
+                                dst = p.llr + (static_cast<size_t>(dsym) * N + O::reg_pos(LAST, h * GO)) * BPS + off;
+                            }
+                            if (ok) {
+                                if constexpr (VW == 4) {
+                                    const float4 q4 = *reinterpret_cast<const float4*>(src);
+                                    stream_store4(dst, q4.x, q4.y, q4.z, q4.w);
+                                } else {
+                                    const float2 q2 = *reinterpret_cast<const float2*>(src);
+                                    stream_store2(dst, q2.x, q2.y);
+                                }
                             }
                         });
                         __builtin_amdgcn_wave_barrier();
