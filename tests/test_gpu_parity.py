@@ -288,7 +288,26 @@ def test_demod_with_equaliser_sets(ctx, oracle, n, cp, bps):
     assert oracle.count_bit_errors(ref["hard"], bits) < 0.02 * bits.size * 8
 
 
-@pytest.mark.parametrize("n,cp,bps", [(64, 16, 2), (256, 64, 4), (1024, 256, 4), (1024, 256, 6), (2048, 512, 6), (4096, 1024, 8), (512, 128, 2)])
+@pytest.mark.parametrize("n", [64, 128, 256, 512, 1024, 2048, 4096, 8192])
+@pytest.mark.parametrize("bps", [2, 4, 6, 8, 10])
+def test_demod_llr_only_every_shape(ctx, oracle, n, bps):
+    """The headline instantiation (LLRs as the only output, no taps) for every tuned size and order,
+    with a symbol count that leaves the last wave of the small sizes partly empty."""
+    from sdr_amd.link import noise_sigma, llr_weight
+    cp = n // 4
+    n_sym = 13 if n <= 2048 else 5
+    ebn0 = {2: 5.0, 4: 9.0, 6: 14.0, 8: 19.0, 10: 24.0}[bps]
+    rx, _ = oracle.link_generate(n, cp, bps, 17 * n + bps, 2, n_sym, np.float32(noise_sigma(n, bps, ebn0)))
+    w = np.float32(llr_weight(bps, ebn0))
+    ref = oracle.demod(rx, n, cp, bps, weight=w, want_fft=False, want_hard=False)
+    guard = torch.full((n_sym * n * bps + 64,), 7.5, dtype=torch.float32, device="cuda")      # nothing may land behind the last symbol
+    out = ctx.demod(dev(rx), n, cp, bps, llr_weight=float(w), out_llr=guard[: n_sym * n * bps].view(n_sym, n, bps))
+    assert same(out.llr.cpu().numpy(), ref["llr"])
+    assert bool((guard[n_sym * n * bps:] == 7.5).all())
+
+
+@pytest.mark.parametrize("n,cp,bps", [(64, 16, 2), (256, 64, 4), (1024, 256, 4), (1024, 256, 6), (2048, 512, 6), (4096, 1024, 8), (512, 128, 2),
+                                      (128, 32, 6), (256, 64, 8), (64, 16, 6)])
 @pytest.mark.parametrize("which", ["both", "taps", "weights"])
 def test_demod_llr_only_with_taps_or_weights(ctx, oracle, n, cp, bps, which):
     """LLR-only output takes the tap-prefetching instantiation; either array may be absent."""
