@@ -415,12 +415,13 @@ struct RxShape {
     static constexpr int STG_BYTES = STG_WAVE_BYTES * (O::kWG / 64);
     // The staging strips reuse the exchange region when they fit: it is dead between the last
     // exchange read and the next symbol's first exchange write.  Multi-wave workgroups need a
-    // barrier for it, which costs more than it gains at N = 2048/4096 (measured); at N = 8192 it is
-    // the difference between one and two workgroups per CU.
+    // barrier for it, which costs more than it gains at N = 2048/4096 (measured) unless LDS is short:
+    // the FULL variants there gain a workgroup per CU (4096/256-QAM + hard bits: 53 -> 59 %), and at
+    // N = 8192 it is the difference between one and two workgroups per CU.
 #ifdef SDR_NO_STG_ALIAS
     static constexpr bool STG_ALIAS = false;
 #else
-    static constexpr bool STG_ALIAS = STAGE && STG_BYTES <= DATA_BYTES && (O::kWG == 64 || LOG2N >= SDR_ALIAS_FROM);
+    static constexpr bool STG_ALIAS = STAGE && STG_BYTES <= DATA_BYTES && (O::kWG == 64 || LOG2N >= SDR_ALIAS_FROM || FULL);
 #endif
     static constexpr int STG_OFF = STG_ALIAS ? 0 : (DATA_BYTES + TW_BYTES + IDX_BYTES + REF_BYTES + 15) & ~15;
     static constexpr int LDS_BYTES = (STG_ALIAS ? DATA_BYTES + TW_BYTES + IDX_BYTES + REF_BYTES : STG_OFF + STG_BYTES) + 16;
@@ -606,6 +607,7 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
                 load_taps();
             }
         }
+        if constexpr (LATE_TAPS && SDR_LATE_AT < 0) load_taps();      // per symbol, but still ahead of the samples
 
         // Reference bits of the symbol (counting only): requested ahead of the samples, parked
         // in LDS before the transform.  Unconditional (see the taps above); a
@@ -641,8 +643,8 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
         }
 
         if constexpr (LATE_TAPS) {
-            auto late = [&]() { load_taps(); };
-            fft_run<LOG2N, false, decltype(late), SDR_LATE_AT>(x, lds_data, addr, tw, std::move(late));
+            auto late = [&]() { if constexpr (SDR_LATE_AT >= 0) load_taps(); };
+            fft_run<LOG2N, false, decltype(late), (SDR_LATE_AT < 0 ? 0 : SDR_LATE_AT)>(x, lds_data, addr, tw, std::move(late));
         } else {
             fft_run<LOG2N>(x, lds_data, addr, tw);
         }
