@@ -327,6 +327,19 @@ __device__ __forceinline__ void fft_run(float2 (&x)[PlanOps<LOG2N>::kE], unsigne
     });
 }
 
+#ifndef SDR_UNIFORM_BASE
+#define SDR_UNIFORM_BASE 0
+#endif
+// a pointer that is the same in every lane, moved to scalar registers
+template <typename T>
+__device__ __forceinline__ T* uniform_ptr(T* p)
+{
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v));
+    const unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v >> 32));
+    return reinterpret_cast<T*>((static_cast<unsigned long long>(hi) << 32) | lo);
+}
+
 typedef float sdr_v4f __attribute__((ext_vector_type(4)));
 typedef float sdr_v2f __attribute__((ext_vector_type(2)));
 
@@ -371,6 +384,9 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
     return v;
 }
 
+#ifndef SDR_EQ_UNROLL
+#define SDR_EQ_UNROLL 1
+#endif
 #ifndef SDR_LATE_AT
 #define SDR_LATE_AT 0
 #endif
@@ -490,8 +506,8 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
     [[maybe_unused]] unsigned char* lds_ref = lds + DATA_BYTES + TW_BYTES + IDX_BYTES;
 
     const int tid = threadIdx.x;
-    const int slot = tid / TPS;
-    const int t = tid % TPS;
+    const int slot = SPW == 1 ? 0 : tid / TPS;
+    const int t = SPW == 1 ? tid : tid % TPS;
 
     // ---- per-workgroup set-up: addresses and twiddles ----
     FftAddr<LOG2N> addr;
@@ -557,8 +573,14 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
     if (grp_begin < grp_end) load_symbol(grp_begin, xn);
 #endif
     if (grp_begin >= grp_end) return;      // uniform over the workgroup
+#if SDR_EQ_UNROLL
+    // tap-holding variants: a run of two groups, written out twice (a loop around barriers does not
+    // unroll, and anything hoisted out of a rolled loop costs registers the transform needs)
+    auto process = [&](const unsigned long long grp) __attribute__((always_inline)) {
+#else
     unsigned long long grp = grp_begin;
     do {
+#endif
         unsigned long long sym = grp * SPW + slot;
         const bool active = sym < p.n_sym;
         if (!active) sym = p.n_sym - 1;
@@ -705,7 +727,7 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
                         store_floats<CHUNK>(stg + lane * (STG_STRIDE / 4), l);
                         __builtin_amdgcn_wave_barrier();
                         constexpr int gbits = O::kLogE - P::kR[LAST];
-                        float* gbase = p.llr + (bin0 + O::reg_pos(LAST, h * GO) + ((tid & ~63) << gbits)) * BPS;
+                        [[maybe_unused]] float* gbase = p.llr + (bin0 + O::reg_pos(LAST, h * GO) + ((tid & ~63) << gbits)) * BPS;
                         static_for<VPL>([&](auto I) {
                             constexpr int i = I;
                             const int v = i * 64 + lane;
@@ -713,7 +735,15 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
                             float* dst;
                             bool ok = true;
                             if constexpr (SPW == 1) {
+#if SDR_UNIFORM_BASE
+                                // the symbol's block starts at a workgroup-uniform address: scalar base +
+                                // 32-bit lane offset keeps the addresses out of the vector registers
+                                float* ubase = uniform_ptr(p.llr + (bin0 + O::reg_pos(LAST, h * GO)) * BPS);
+                                const unsigned loff = (static_cast<unsigned>(tid & ~63) << gbits) * BPS + static_cast<unsigned>(v) * VW;
+                                dst = ubase + loff;
+#else
                                 dst = gbase + v * VW;
+#endif
                             } else {
                                 constexpr int RUN = TPS * CHUNK;                 // floats per symbol in this block
                                 static_assert(RUN % VW == 0, "vectors do not straddle symbols");
@@ -799,8 +829,19 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
                 }
             }
         }
+#if SDR_EQ_UNROLL
+    };
+    process(grp_begin);
+    if constexpr (LOOP) {
+        if (grp_begin + 1 < grp_end) {                 // uniform over the workgroup
+            __syncthreads();                           // LDS regions are reused by the next symbol group
+            process(grp_begin + 1);
+        }
+    }
+#else
         if constexpr (LOOP) __syncthreads();   // LDS regions are reused by the next symbol group
     } while (LOOP && ++grp < grp_end);
+#endif
 
     if constexpr (FULL && DEMAP) {
         if (p.counters) {
@@ -860,6 +901,9 @@ int launch_rx_fused(sdr_ctx* ctx, const RxParams& p)
     unsigned long long per_wg = p.counters ? 8 : EQ ? 2 : 1;
     if (tune.groups_per_wg >= 0) per_wg = static_cast<unsigned long long>(tune.groups_per_wg);
     if (!LOOP) per_wg = 1;
+#if SDR_EQ_UNROLL
+    else per_wg = 2;
+#endif
     if (per_wg == 0 || tune.debug) {
         int nb = 0;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, O::kWG, static_cast<size_t>(tune.lds_pad > 0 ? tune.lds_pad : 0));
