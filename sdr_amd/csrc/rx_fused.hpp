@@ -16,18 +16,21 @@
 // Built with -ffp-contract=off, so every product and sum rounds separately as on the CPU.
 //
 // Mapping: TPS = N/E threads per symbol; a workgroup is max(64, TPS) threads = 64/TPS symbols
-// (small N) or one symbol (N >= 1024) and handles a short run of consecutive symbol groups.
-// Twiddles: first pass = lane-uniform (scalar registers), middle pass = small LDS table, last
-// pass = per-thread registers loaded once per workgroup.
+// (small N) or one symbol (N >= 1024) and handles ONE symbol group as straight-line code (the
+// tap-holding variants: two).  Twiddles: first pass = lane-uniform (scalar registers), middle pass =
+// small LDS table, last pass = per-thread registers loaded once per workgroup.
 // HBM traffic per symbol: 8*N bytes read (CP never fetched) + 4*N*bps bytes of LLR written.
 //
-// Instantiations <LOG2N, MI, MQ, FULL, EQ>: MI/MQ = bits on the I/Q axis (0,0 = FFT only);
-// FULL = hard bits / bins / counters optional at run time; EQ = per-subcarrier taps / weights
-// held in registers.  Compile-time experiment switches kept for A/B measurements (all measured
-// neutral or worse): SDR_WPE=<n> (force waves per SIMD), SDR_PREFETCH
-// (load the next symbol before storing this one), SDR_NT_LOADS (non-temporal sample loads),
-// SDR_PLAIN_STORES (LLR stores without the non-temporal hint),
-// SDR_NO_STAGE8 / SDR_NO_STG_ALIAS (LLR staging variants).  Run-time knobs: see RxTuning.
+// Instantiations <LOG2N, MI, MQ, FULL, EQ, HARDONLY>: MI/MQ = bits on the I/Q axis (0,0 = FFT
+// only); FULL = hard bits / bins / counters optional at run time; EQ = per-subcarrier taps / weights
+// held in registers; HARDONLY = packed hard decisions as the only output.  RxShape holds each
+// instantiation's LDS layout, control structure and waves-per-SIMD bounds.
+// Compile-time experiment switches kept for A/B measurements (DESIGN.md sections 6.1 and 7 give the
+// numbers): SDR_WPE=<n> (force waves per SIMD), SDR_EQ_WPE, SDR_NO_MAX_WAVES (no even-spread cap),
+// SDR_LATE_TAPS / SDR_LATE_TAPS_FULL / SDR_LATE_AT (taps per symbol instead of held), SDR_EQ_SET0,
+// SDR_NT_LOADS (non-temporal sample loads), SDR_PLAIN_STORES (LLR stores without the non-temporal
+// hint), SDR_NO_STAGE8 / SDR_NO_STG_ALIAS / SDR_ALIAS_FROM / SDR_NO_SMALL_STAGE (LLR staging
+// variants).  Run-time knobs: see RxTuning.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -327,19 +330,6 @@ __device__ __forceinline__ void fft_run(float2 (&x)[PlanOps<LOG2N>::kE], unsigne
     });
 }
 
-#ifndef SDR_UNIFORM_BASE
-#define SDR_UNIFORM_BASE 0
-#endif
-// a pointer that is the same in every lane, moved to scalar registers
-template <typename T>
-__device__ __forceinline__ T* uniform_ptr(T* p)
-{
-    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
-    const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v));
-    const unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v >> 32));
-    return reinterpret_cast<T*>((static_cast<unsigned long long>(hi) << 32) | lo);
-}
-
 typedef float sdr_v4f __attribute__((ext_vector_type(4)));
 typedef float sdr_v2f __attribute__((ext_vector_type(2)));
 
@@ -384,9 +374,6 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
     return v;
 }
 
-#ifndef SDR_EQ_UNROLL
-#define SDR_EQ_UNROLL 1
-#endif
 #ifndef SDR_LATE_AT
 #define SDR_LATE_AT 0
 #endif
@@ -451,11 +438,7 @@ struct RxShape {
     // hoisted out of a loop into registers (N = 1024 LLR variant: 136 -> 104-119 registers; hard bits
     // beside LLRs: 63 -> 68 %; N = 8192: 56 -> 71 %).  Counting variants then end every symbol with
     // four atomics per wave on the 1024 counter slots, which measured no slower than runs of eight.
-#ifdef SDR_ALWAYS_LOOP
-    static constexpr bool LOOP = true;
-#else
     static constexpr bool LOOP = EQ && !LATE_TAPS;
-#endif
 
     // Waves per SIMD.  Lower bound = register budget: the tap-holding and FULL variants must not
     // drift to 256+ registers (one wave per SIMD); at N = 8192 (E = 32) FULL variants are held to
@@ -568,19 +551,11 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
     [[maybe_unused]] float2 eqv[EQ ? E : 1];
     [[maybe_unused]] float wv[EQ ? E : 1];
     [[maybe_unused]] size_t held_set = ~static_cast<size_t>(0);     // set whose taps the registers hold
-#ifdef SDR_PREFETCH
-    float2 xn[E];
-    if (grp_begin < grp_end) load_symbol(grp_begin, xn);
-#endif
     if (grp_begin >= grp_end) return;      // uniform over the workgroup
-#if SDR_EQ_UNROLL
-    // tap-holding variants: a run of two groups, written out twice (a loop around barriers does not
-    // unroll, and anything hoisted out of a rolled loop costs registers the transform needs)
+    // One symbol group, as a body that the tap-holding variants run twice: written out, because a
+    // loop around barriers does not unroll and anything hoisted out of a rolled loop costs
+    // registers the transform needs (243 -> 180 at N = 2048).
     auto process = [&](const unsigned long long grp) __attribute__((always_inline)) {
-#else
-    unsigned long long grp = grp_begin;
-    do {
-#endif
         unsigned long long sym = grp * SPW + slot;
         const bool active = sym < p.n_sym;
         if (!active) sym = p.n_sym - 1;
@@ -629,7 +604,6 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
                 load_taps();
             }
         }
-        if constexpr (LATE_TAPS && SDR_LATE_AT < 0) load_taps();      // per symbol, but still ahead of the samples
 
         // Reference bits of the symbol (counting only): requested ahead of the samples, parked
         // in LDS before the transform.  Unconditional (see the taps above); a
@@ -649,12 +623,7 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
         }
 
         // ---- pass 0 ----
-#ifdef SDR_PREFETCH
-        static_for<E>([&](auto M) { constexpr int m = M; x[m] = xn[m]; });
-        if (grp + 1 < grp_end) load_symbol(grp + 1, xn);   // in flight during this symbol's compute
-#else
         load_symbol(grp, x);
-#endif
         if constexpr (FULL && DEMAP) {
             static_for<REF_PER_THREAD>([&](auto R) {
                 constexpr int r = R;
@@ -665,8 +634,8 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
         }
 
         if constexpr (LATE_TAPS) {
-            auto late = [&]() { if constexpr (SDR_LATE_AT >= 0) load_taps(); };
-            fft_run<LOG2N, false, decltype(late), (SDR_LATE_AT < 0 ? 0 : SDR_LATE_AT)>(x, lds_data, addr, tw, std::move(late));
+            auto late = [&]() { load_taps(); };
+            fft_run<LOG2N, false, decltype(late), SDR_LATE_AT>(x, lds_data, addr, tw, std::move(late));
         } else {
             fft_run<LOG2N>(x, lds_data, addr, tw);
         }
@@ -727,7 +696,7 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
                         store_floats<CHUNK>(stg + lane * (STG_STRIDE / 4), l);
                         __builtin_amdgcn_wave_barrier();
                         constexpr int gbits = O::kLogE - P::kR[LAST];
-                        [[maybe_unused]] float* gbase = p.llr + (bin0 + O::reg_pos(LAST, h * GO) + ((tid & ~63) << gbits)) * BPS;
+                        float* gbase = p.llr + (bin0 + O::reg_pos(LAST, h * GO) + ((tid & ~63) << gbits)) * BPS;
                         static_for<VPL>([&](auto I) {
                             constexpr int i = I;
                             const int v = i * 64 + lane;
@@ -735,15 +704,7 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
                             float* dst;
                             bool ok = true;
                             if constexpr (SPW == 1) {
-#if SDR_UNIFORM_BASE
-                                // the symbol's block starts at a workgroup-uniform address: scalar base +
-                                // 32-bit lane offset keeps the addresses out of the vector registers
-                                float* ubase = uniform_ptr(p.llr + (bin0 + O::reg_pos(LAST, h * GO)) * BPS);
-                                const unsigned loff = (static_cast<unsigned>(tid & ~63) << gbits) * BPS + static_cast<unsigned>(v) * VW;
-                                dst = ubase + loff;
-#else
                                 dst = gbase + v * VW;
-#endif
                             } else {
                                 constexpr int RUN = TPS * CHUNK;                 // floats per symbol in this block
                                 static_assert(RUN % VW == 0, "vectors do not straddle symbols");
@@ -829,7 +790,6 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
                 }
             }
         }
-#if SDR_EQ_UNROLL
     };
     process(grp_begin);
     if constexpr (LOOP) {
@@ -838,10 +798,6 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
             process(grp_begin + 1);
         }
     }
-#else
-        if constexpr (LOOP) __syncthreads();   // LDS regions are reused by the next symbol group
-    } while (LOOP && ++grp < grp_end);
-#endif
 
     if constexpr (FULL && DEMAP) {
         if (p.counters) {
@@ -862,18 +818,15 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
 
 // Tuning knobs, read from the environment once per process (measurement aids; the defaults are
 // what the benchmarks and tests run):
-//   SDR_GROUPS_PER_WG  symbol groups per workgroup (0 = one resident grid striding over the batch)
 //   SDR_XCD_WINDOW     window of the XCD-aware workgroup-id permutation (0 = off)
 //   SDR_LDS_PAD        bytes of unused dynamic LDS per workgroup (occupancy experiments)
 //   SDR_DEBUG          print each instantiation's launch shape once
 struct RxTuning {
-    long groups_per_wg = -1;      // -1: default
     long xcd_window = 4096;
     long lds_pad = 0;             // extra dynamic LDS per workgroup: throttles resident workgroups per CU
     bool debug = false;
     RxTuning()
     {
-        if (const char* v = getenv("SDR_GROUPS_PER_WG")) groups_per_wg = atol(v);
         if (const char* v = getenv("SDR_XCD_WINDOW")) xcd_window = atol(v) & ~7L;
         if (const char* v = getenv("SDR_LDS_PAD")) lds_pad = atol(v);
         debug = getenv("SDR_DEBUG") != nullptr;
@@ -892,31 +845,17 @@ int launch_rx_fused(sdr_ctx* ctx, const RxParams& p)
     auto kern = rx_fused_kernel<LOG2N, MI, MQ, FULL, EQ, HARDONLY>;
     const RxTuning& tune = rx_tuning();
     const unsigned long long n_groups = (p.n_sym + O::kSPW - 1) / O::kSPW;
-    // Each workgroup takes a run of consecutive symbol groups.  With the XCD-aware order one group
-    // per workgroup measured best (+1.5 to +5 points over two at N = 512 ... 4096; the per-workgroup
-    // twiddle set-up is cheap, the finer grain balances better), and far better than a resident
-    // grid striding over the batch.  Two exceptions: the tap-holding variants reload their taps
-    // once per run (two groups: 64 % against 57 %), and counting ends every workgroup with atomics.
-    constexpr bool LOOP = RxShape<LOG2N, MI, MQ, FULL, EQ, HARDONLY>::LOOP;
-    unsigned long long per_wg = p.counters ? 8 : EQ ? 2 : 1;
-    if (tune.groups_per_wg >= 0) per_wg = static_cast<unsigned long long>(tune.groups_per_wg);
-    if (!LOOP) per_wg = 1;
-#if SDR_EQ_UNROLL
-    else per_wg = 2;
-#endif
-    if (per_wg == 0 || tune.debug) {
+    // One symbol group per workgroup (with the XCD-aware order: +1.5 to +5 points over runs of two
+    // at N = 512 ... 4096, and far better than a resident grid striding over the batch; the
+    // per-workgroup twiddle set-up is cheap, the finer grain balances better).  The tap-holding
+    // variants take two, reloading their taps once per run (65 % against 61 %).
+    const unsigned long long per_wg = RxShape<LOG2N, MI, MQ, FULL, EQ, HARDONLY>::LOOP ? 2 : 1;
+    if (tune.debug) {
         int nb = 0;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, O::kWG, static_cast<size_t>(tune.lds_pad > 0 ? tune.lds_pad : 0));
         if (e != hipSuccess) return fail_hip(e, "hipOccupancyMaxActiveBlocksPerMultiprocessor");
-        if (nb < 1) nb = 1;
-        if (tune.debug) fprintf(stderr, "[sdr] rx_fused<%d,%d,%d,%d,%d,%d>: %d threads/WG, %d WG/CU, %d CUs\n", LOG2N, MI, MQ, int(FULL), int(EQ), int(HARDONLY), O::kWG, nb, ctx->num_cu);
-        if (per_wg == 0) {
-            const unsigned long long resident = static_cast<unsigned long long>(ctx->num_cu) * nb;
-            per_wg = (n_groups + resident - 1) / resident;
-        }
+        fprintf(stderr, "[sdr] rx_fused<%d,%d,%d,%d,%d,%d>: %d threads/WG, %d WG/CU, %d CUs\n", LOG2N, MI, MQ, int(FULL), int(EQ), int(HARDONLY), O::kWG, nb, ctx->num_cu);
     }
-    if (per_wg > 0xFFFFFFFFull) per_wg = 0xFFFFFFFFull;
-    if (per_wg == 0) per_wg = 1;
     const unsigned long long blocks = (n_groups + per_wg - 1) / per_wg;
     if (blocks > 0x7FFFFFFFull) return fail(SDR_ERR_UNSUPPORTED, "batch too large for one launch");
     RxParams q = p;
