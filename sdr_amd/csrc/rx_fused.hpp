@@ -374,6 +374,9 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
     return v;
 }
 
+#ifndef SDR_LINEAR_STRIP
+#define SDR_LINEAR_STRIP 1
+#endif
 #ifndef SDR_LATE_AT
 #define SDR_LATE_AT 0
 #endif
@@ -689,20 +692,25 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
                     // wave = SPW symbols): one contiguous run of TPS * CHUNK floats per symbol, so the
                     // copy is wave-wide and checks the destination symbol, not the lane's own.
                     if (p.llr && (SPW > 1 || active)) {
-                        constexpr int VW = (CHUNK % 4 == 0) ? 4 : 2;            // floats per vector
-                        constexpr int VPL = CHUNK / VW;                          // vectors per lane
+                        // a strip without padding is linear memory: 16-byte vectors may straddle lanes
+                        constexpr bool LINEAR = SDR_LINEAR_STRIP && STG_STRIDE == CHUNK * 4 && (64 * CHUNK) % 4 == 0;
+                        constexpr int VW = (CHUNK % 4 == 0 || LINEAR) ? 4 : 2;   // floats per vector
+                        constexpr int NV = 64 * CHUNK / VW;                      // vectors per wave and block
+                        constexpr int VPL = CHUNK / VW;                          // vectors per lane (padded strips)
                         const int lane = tid & 63;
                         float* stg = reinterpret_cast<float*>(lds + STG_OFF + (tid >> 6) * STG_WAVE_BYTES);
                         store_floats<CHUNK>(stg + lane * (STG_STRIDE / 4), l);
                         __builtin_amdgcn_wave_barrier();
                         constexpr int gbits = O::kLogE - P::kR[LAST];
                         float* gbase = p.llr + (bin0 + O::reg_pos(LAST, h * GO) + ((tid & ~63) << gbits)) * BPS;
-                        static_for<VPL>([&](auto I) {
+                        static_for<(NV + 63) / 64>([&](auto I) {
                             constexpr int i = I;
                             const int v = i * 64 + lane;
-                            const float* src = stg + (v / VPL) * (STG_STRIDE / 4) + (v % VPL) * VW;
+                            const float* src;
+                            if constexpr (LINEAR) src = stg + v * VW;
+                            else src = stg + (v / VPL) * (STG_STRIDE / 4) + (v % VPL) * VW;
                             float* dst;
-                            bool ok = true;
+                            bool ok = (NV % 64 == 0) || v < NV;
                             if constexpr (SPW == 1) {
                                 dst = gbase + v * VW;
                             } else {
@@ -710,7 +718,7 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
                                 static_assert(RUN % VW == 0, "vectors do not straddle symbols");
                                 const int s_ = (v * VW) / RUN, off = (v * VW) % RUN;
                                 const unsigned long long dsym = grp * SPW + s_;
-                                ok = dsym < p.n_sym;
+                                ok = ok && dsym < p.n_sym;
                                 dst = p.llr + (static_cast<size_t>(dsym) * N + O::reg_pos(LAST, h * GO)) * BPS + off;
                             }
                             if (ok) {
