@@ -15,6 +15,10 @@
 
 #include <hip/hip_runtime.h>
 
+#ifndef SDR_FAST_FROM
+#define SDR_FAST_FROM 3      // hard decision alone: bits per axis from which the three-point test replaces the scan
+#endif
+
 namespace sdr {
 
 template <typename T> struct FltMax;
@@ -168,7 +172,7 @@ __device__ inline unsigned demap_point(T re, T im, T inorm, T w, T* llr)
     const T ui = im * inorm;
     if constexpr (!WANT_LLR) {
         // hard decision alone: no need for every distance (4-level axes gain nothing from it)
-        if constexpr (WANT_IDX && (MI > 2 || MQ > 2)) return nearest_fast<T, MI, MQ>(ur, ui);
+        if constexpr (WANT_IDX && (MI >= SDR_FAST_FROM || MQ >= SDR_FAST_FROM)) return nearest_fast<T, MI, MQ>(ur, ui);
     }
     T dx[1 << MI];
     T dy[1 << MQ];
