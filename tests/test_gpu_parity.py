@@ -119,7 +119,7 @@ def test_fft2_golden(ctx):
 
 # ---- ofdm::rx / tx batched -------------------------------------------------------------------
 @pytest.mark.parametrize("n,cp", [(8, 8), (64, 16), (256, 64), (1024, 256), (2048, 512), (4096, 1024), (128, 0), (512, 37), (128, 32), (512, 128),
-                                  (16, 4), (8192, 2048), (1024, 1024)])
+                                  (16, 4), (8192, 2048), (1024, 1024), (1024, 37), (2048, 1), (8192, 3), (4096, 5)])
 def test_ofdm_rx_tx_bit_exact(ctx, oracle, n, cp):
     rng = np.random.default_rng(n + cp)
     s = 7
