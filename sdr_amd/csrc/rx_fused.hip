@@ -144,7 +144,8 @@ int copy_shape_launch(sdr_ctx* ctx, const void* d_rx, uint32_t n_fft, uint32_t c
     if (blocks > 0x7FFFFFFFull) return fail(SDR_ERR_UNSUPPORTED, "batch too large for one launch");
     const RxTuning& tune = rx_tuning();
     hipLaunchKernelGGL(copy_shape_kernel, dim3(static_cast<unsigned>(blocks)), dim3(64), 0, ctx->stream, static_cast<const float4*>(d_rx), d_out,
-                       n_fft, cp, bps, static_cast<unsigned long long>(n_sym), static_cast<unsigned>(tune.xcd_window > 0 ? tune.xcd_window : 0));
+                       n_fft, cp, bps, static_cast<unsigned long long>(n_sym),
+                       static_cast<unsigned>(tune.xcd_window > 0 ? (static_cast<unsigned long long>(tune.xcd_window) < (blocks & ~7ull) ? static_cast<unsigned long long>(tune.xcd_window) : (blocks & ~7ull)) : 0));      // same clipped window as the receive kernel
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(e, "copy_shape_kernel launch");
     return SDR_OK;

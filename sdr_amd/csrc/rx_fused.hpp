@@ -537,7 +537,9 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
     // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 shares an XCD).  Inside
     // windows of xcd_window workgroups the ids are permuted so that each XCD works on a run of
     // CONSECUTIVE symbols: its stores then form one sequential stream instead of every eighth
-    // chunk (measured +6..10 % on the write path, tools/membench2/3).  Speed only, never correctness.
+    // chunk (measured +6..10 % on the write path, tools/membench2/3).  The default window is the
+    // whole grid (one contiguous eighth of the batch per XCD: +1 to +3 points over windows of 4096
+    // on 1 Mi-symbol batches, tools/sweep_xcd_window.sh).  Speed only, never correctness.
     unsigned long long wg = blockIdx.x;
     if (p.xcd_window >= 8) {
         const unsigned long long win = p.xcd_window;
@@ -830,7 +832,7 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
 //   SDR_LDS_PAD        bytes of unused dynamic LDS per workgroup (occupancy experiments)
 //   SDR_DEBUG          print each instantiation's launch shape once
 struct RxTuning {
-    long xcd_window = 4096;
+    long xcd_window = 1L << 30;   // clipped to the grid: every XCD takes one contiguous eighth of the batch
     long lds_pad = 0;             // extra dynamic LDS per workgroup: throttles resident workgroups per CU
     bool debug = false;
     RxTuning()
@@ -868,7 +870,9 @@ int launch_rx_fused(sdr_ctx* ctx, const RxParams& p)
     if (blocks > 0x7FFFFFFFull) return fail(SDR_ERR_UNSUPPORTED, "batch too large for one launch");
     RxParams q = p;
     q.groups_per_wg = static_cast<uint32_t>(per_wg);
-    q.xcd_window = static_cast<uint32_t>(tune.xcd_window > 0 ? tune.xcd_window : 0);
+    // never wider than the grid: a batch smaller than the window would otherwise run unpermuted
+    const unsigned long long win = tune.xcd_window > 0 ? static_cast<unsigned long long>(tune.xcd_window) : 0;
+    q.xcd_window = static_cast<uint32_t>(win < (blocks & ~7ull) ? win : (blocks & ~7ull));
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(O::kWG), static_cast<size_t>(tune.lds_pad > 0 ? tune.lds_pad : 0), ctx->stream, q);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(e, "rx_fused_kernel launch");
