@@ -160,17 +160,53 @@ __global__ void __launch_bounds__(256) from_constl_kernel(const T* __restrict__ 
     }
 }
 
+// Max-log LLRs of a symbol array.  From 6 bits per symbol up, a lane's LLRs (24-40 bytes) go through
+// a per-wave LDS strip so that every store instruction writes 1 KiB contiguous (per-lane chunks cap a
+// copy of this shape at 3 TB/s, tools/membench); the narrower orders store a lane's 4-16 bytes directly.
 template <int MI, int MQ>
-__global__ void soft_demap_kernel(const float* __restrict__ sym, size_t n_sym, float inorm, const float* __restrict__ wgt, float w0,
-                                  float* __restrict__ llr)
+__global__ void __launch_bounds__(256) soft_demap_kernel(const float* __restrict__ sym, size_t n_sym, float inorm, const float* __restrict__ wgt, float w0,
+                                                         float* __restrict__ llr, bool wide_ok)
 {
     constexpr int BPS = MI + MQ;
+    constexpr bool STAGED = BPS >= 6 && (64 * BPS) % 4 == 0;
+    __shared__ __attribute__((aligned(16))) float strip[STAGED ? 4 : 1][STAGED ? 64 * BPS : 4];
     const ItemRange range = xcd_item_range(n_sym);
-    for (size_t k = range.first; k < range.last; k += range.step) {
+    const int lane = threadIdx.x & 63;
+    // wave-uniform trip count: first - lane is the wave's first item
+    for (size_t k0 = range.first - lane; k0 < range.last; k0 += range.step) {
+        const size_t k = k0 + lane;
         float l[BPS];
-        demap_point<float, MI, MQ, true, false>(sym[2 * k], sym[2 * k + 1], inorm, wgt ? wgt[k] : w0, l);
+        if (k < range.last) demap_point<float, MI, MQ, true, false>(sym[2 * k], sym[2 * k + 1], inorm, wgt ? wgt[k] : w0, l);
+        if constexpr (STAGED) {
+            if (wide_ok) {
+                float* mine = strip[threadIdx.x >> 6];
+                if (k < range.last) {
 #pragma unroll
-        for (int b = 0; b < BPS; ++b) llr[k * BPS + b] = l[b];
+                    for (int b = 0; b < BPS; ++b) mine[lane * BPS + b] = l[b];
+                }
+                __builtin_amdgcn_wave_barrier();     // one wave: its LDS operations complete in order
+                const size_t n_here = (range.last - k0 < 64 ? range.last - k0 : 64) * BPS;      // floats of this wave's span
+                float* dst = llr + k0 * BPS;
+#pragma unroll
+                for (int i = 0; i < BPS / 4 + (BPS % 4 != 0); ++i) {
+                    const size_t f = (static_cast<size_t>(i) * 64 + lane) * 4;
+                    if (f + 4 <= n_here) {
+                        const float4 q = *reinterpret_cast<const float4*>(mine + f);
+                        typedef float vec4 __attribute__((ext_vector_type(4)));
+                        const vec4 v = {q.x, q.y, q.z, q.w};
+                        __builtin_nontemporal_store(v, reinterpret_cast<vec4*>(dst + f));
+                    } else {
+                        for (size_t j = f; j < n_here && j < f + 4; ++j) dst[j] = mine[j];
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                continue;
+            }
+        }
+        if (k < range.last) {
+#pragma unroll
+            for (int b = 0; b < BPS; ++b) llr[k * BPS + b] = l[b];
+        }
     }
 }
 
@@ -318,7 +354,8 @@ int soft_demap_dev(sdr_ctx* ctx, int mod, const void* d_sym, size_t n_sym, const
     if (!d_sym || !d_llr) return fail(SDR_ERR_INVALID, "null device pointer");
     const unsigned grid = grid_for(ctx, n_sym);
     dispatch_mod(mod, [&]<int MI, int MQ>() {
-        hipLaunchKernelGGL((soft_demap_kernel<MI, MQ>), dim3(grid), dim3(kThreads), 0, ctx->stream, static_cast<const float*>(d_sym), n_sym, inorm_in<float>(mod), d_weight, weight0, d_llr);
+        hipLaunchKernelGGL((soft_demap_kernel<MI, MQ>), dim3(grid), dim3(kThreads), 0, ctx->stream, static_cast<const float*>(d_sym), n_sym, inorm_in<float>(mod), d_weight, weight0, d_llr,
+                           reinterpret_cast<uintptr_t>(d_llr) % 16 == 0);
     });
     SDR_HIP(hipGetLastError());
     return SDR_OK;

@@ -140,10 +140,13 @@ class Context:
         check(fn(self._h, bps, _ptr(sym), sym.numel(), _ptr(out)))
         return out
 
-    def soft_demap(self, sym: torch.Tensor, mod, weight=1.0) -> torch.Tensor:
+    def soft_demap(self, sym: torch.Tensor, mod, weight=1.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         bps = mod_bits(mod)
         _need(sym, torch.complex64, "sym")
-        out = torch.empty((sym.numel(), bps), dtype=torch.float32, device=sym.device)
+        if out is None:
+            out = torch.empty((sym.numel(), bps), dtype=torch.float32, device=sym.device)
+        else:
+            _need(out, torch.float32, "out", sym.numel() * bps)
         wt = weight if isinstance(weight, torch.Tensor) else None
         w0 = 0.0 if wt is not None else float(weight)
         if wt is not None:

@@ -205,6 +205,20 @@ def test_nearest_adversarial_points_bit_exact(ctx, oracle, bps, dt):
     assert same(ctx.from_constl(dev(pts[:k]), bps).cpu().numpy(), want_bytes)
 
 
+@pytest.mark.parametrize("bps", [2, 6, 8, 10])
+@pytest.mark.parametrize("n_sym", [1, 63, 64, 65, 257, 2048 + 5, (1 << 20) + 77])
+def test_soft_demap_ragged_sizes(ctx, oracle, bps, n_sym):
+    """Soft demapping at sizes that leave the last wave partly empty, in a grid that is / is not a
+    multiple of the XCD count, with nothing written behind the last LLR."""
+    rng = np.random.default_rng(n_sym + bps)
+    pts = rand_c(rng, n_sym) * np.float32(0.8)
+    want = oracle.soft_demap(bps, pts, 1.25)
+    guard = torch.full((n_sym * bps + 64,), -3.5, dtype=torch.float32, device="cuda")
+    got = ctx.soft_demap(dev(pts), bps, 1.25, out=guard[: n_sym * bps].view(n_sym, bps))
+    assert same(got.cpu().numpy().reshape(want.shape), want)
+    assert bool((guard[n_sym * bps:] == -3.5).all())
+
+
 @pytest.mark.parametrize("bps", [1, 2, 4, 6, 8, 10])
 def test_nearest_random_noise_bit_exact(ctx, oracle, bps):
     rng = np.random.default_rng(40 + bps)
