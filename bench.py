@@ -200,9 +200,14 @@ def main():
     main_res = time_workload(ctx, torch, dist, args.workload, args.steps, args.warmup, world, rank, args.symbols or None)
     extra = {}
     if world == 1 and not args.no_extra and args.workload == "fft1024_16qam_1M" and not args.symbols:
-        r = time_workload(ctx, torch, dist, "fft1024_64qam_1M", max(3, args.steps // 2), 2, 1, 0)
+        r = time_workload(ctx, torch, dist, "fft1024_64qam_1M", max(3, args.steps // 2), 5, 1, 0)
         extra["fft1024_64qam_1M"] = {"sym_per_s": r["sym_per_s"], "llr_gbit_per_s": r["sym_per_s"] * r["n_fft"] * r["bps"] / 1e9,
                                      "hbm_frac": r["roofline"]["frac"], "achieved_GBs": r["roofline"]["achieved"]}
+        # the other configurations of BASELINE.json's list, for the record (not bench lines)
+        for name in ("fft2048_64qam_eq", "fft4096_256qam", "fft64_qpsk"):
+            r = time_workload(ctx, torch, dist, name, max(3, args.steps // 2), 5, 1, 0)
+            extra[name] = {"sym_per_s": r["sym_per_s"], "llr_gbit_per_s": r["sym_per_s"] * r["n_fft"] * r["bps"] / 1e9,
+                           "hbm_frac": r["roofline"]["frac"], "achieved_GBs": r["roofline"]["achieved"], "symbols": r["n_sym"]}
     if main_res.get("copy_shape_gbs"):
         extra["copy_of_same_shape"] = {"achieved_GBs": main_res["copy_shape_gbs"], "kernel_over_copy": main_res["roofline"]["achieved"] / main_res["copy_shape_gbs"],
                                        "what": "sdr_diag_copy_shape_c32: the kernel's bytes and access pattern with no arithmetic, same buffers"}
