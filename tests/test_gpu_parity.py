@@ -304,6 +304,64 @@ def test_demod_with_equaliser_sets(ctx, oracle, n, cp, bps):
     assert oracle.count_bit_errors(ref["hard"], bits) < 0.02 * bits.size * 8
 
 
+def _random_demod_cases(count=64, seed=20261111):
+    rng = np.random.default_rng(seed)
+    cases = []
+    for i in range(count):
+        n = int(rng.choice([64, 128, 256, 512, 1024, 2048, 4096, 8192]))
+        cp = int(rng.choice([0, n // 4, 2 * int(rng.integers(0, n // 2 + 1))]))
+        bps = int(rng.choice([1, 2, 4, 6, 8, 10]))
+        n_sym = int(rng.integers(1, 36 if n <= 1024 else 12))
+        taps = str(rng.choice(["none", "none", "both", "taps", "weights"]))
+        outs = int(rng.integers(1, 16))                  # bit 0 llr, 1 hard, 2 bins, 3 counters (needs hard reference)
+        cases.append((i, n, cp, bps, n_sym, taps, outs))
+    return cases
+
+
+@pytest.mark.parametrize("i,n,cp,bps,n_sym,taps,outs", _random_demod_cases())
+def test_demod_random_configurations(ctx, oracle, i, n, cp, bps, n_sym, taps, outs):
+    """Seeded sweep over size x prefix x order x batch x taps/weights x requested outputs: whichever
+    instantiation the dispatch picks, every output it produces equals the oracle's."""
+    from sdr_amd.link import noise_sigma
+    rng = np.random.default_rng(1000 + i)
+    per = int(rng.integers(1, 9))
+    n_sets = (n_sym + per - 1) // per
+    h = (rand_c(rng, (n_sets, n)) * np.float32(np.sqrt(0.5))).astype(np.complex64)
+    h[np.abs(h) < 0.1] += np.float32(0.3)
+    use_chan = taps in ("both", "taps")
+    ebn0 = {1: 6.0, 2: 7.0, 4: 11.0, 6: 16.0, 8: 21.0, 10: 26.0}[bps]
+    # first symbol on a set boundary: the generator's channel sets then line up with the demodulator's
+    rx, bits = oracle.link_generate(n, cp, bps, 77 + i, i * per, n_sym, np.float32(noise_sigma(n, bps, ebn0)),
+                                    chan=(h if use_chan else None), sym_per_set=(per if use_chan else 0))
+    t, w = oracle.zf_taps(bps, h, 9.0)
+    eq = t if taps in ("both", "taps") else None
+    wt = w if taps in ("both", "weights") else np.float32(0.8)
+    sps = per if taps != "none" else 0
+    want_llr, want_hard, want_fft, want_cnt = bool(outs & 1), bool(outs & 2), bool(outs & 4), bool(outs & 8)
+    ref = oracle.demod(rx, n, cp, bps, eq=eq, weight=wt, sym_per_set=sps)
+    counters = torch.zeros(8, dtype=torch.int64, device="cuda") if want_cnt else None
+    out = ctx.demod(dev(rx), n, cp, bps, eq=(dev(eq.ravel()) if eq is not None else None),
+                    llr_weight=(dev(wt.ravel()) if isinstance(wt, np.ndarray) else float(wt)), sym_per_set=sps,
+                    want_llr=want_llr, want_hard=want_hard, want_fft=want_fft,
+                    ref_hard=(dev(bits) if want_cnt else None), counters=counters)
+    if want_llr:
+        assert same(out.llr.cpu().numpy(), ref["llr"])
+    else:
+        assert out.llr is None
+    if want_hard:
+        assert same(out.hard.cpu().numpy(), ref["hard"])
+    if want_fft:
+        assert same(out.fft.cpu().numpy(), ref["fft"])
+    if want_cnt:
+        c = counters.cpu().numpy()
+        assert c[0] == oracle.count_bit_errors(ref["hard"], bits)
+        assert c[1] == n_sym * n * bps and c[3] == n_sym * n and c[4] == n_sym
+        l = ref["llr"].reshape(-1, bps)
+        q = np.minimum(np.abs(l) * np.float32(1024.0), np.float32(1073741824.0)).astype(np.int64)
+        assert c[5] == int(q.sum())
+        assert c[6] == int(((l < 0).astype(np.uint8) != np.unpackbits(bits).reshape(-1, bps)).sum())
+
+
 @pytest.mark.parametrize("n", [64, 128, 256, 512, 1024, 2048, 4096, 8192])
 @pytest.mark.parametrize("bps", [2, 4, 6, 8, 10])
 def test_demod_llr_only_every_shape(ctx, oracle, n, bps):
