@@ -136,6 +136,32 @@ def test_ofdm_rx_tx_bit_exact(ctx, oracle, n, cp):
     assert rel_err(back, fr) < 1e-5
 
 
+def _random_tx_cases(count=32, seed=4242):
+    rng = np.random.default_rng(seed)
+    return [(i, int(rng.choice([16, 64, 128, 256, 512, 1024, 2048, 4096, 8192])), int(rng.integers(1, 20)), int(rng.integers(0, 3)))
+            for i in range(count)]
+
+
+@pytest.mark.parametrize("i,n,n_sym,shift", _random_tx_cases())
+def test_ofdm_tx_rx_random_layouts(ctx, oracle, i, n, n_sym, shift):
+    """Batched ofdm::tx / ofdm::rx with random prefix lengths (odd ones included), batch sizes and
+    buffers that start 0, 8 or 16 bytes into an allocation: every dispatch path equals the oracle."""
+    rng = np.random.default_rng(500 + i)
+    cp = int(rng.integers(0, n + 1))
+    fr = rand_c(rng, (n_sym, n))
+    pool = torch.empty(n_sym * n + 4, dtype=torch.complex64, device="cuda")
+    src = pool[shift: shift + n_sym * n].view(n_sym, n)
+    src.copy_(dev(fr))
+    rc, ref = oracle.ofdm_tx(fr, n, cp)
+    tx = ctx.ofdm_tx(src, n, cp)
+    assert same(tx.cpu().numpy(), ref)
+    rpool = torch.empty(n_sym * (n + cp) + 4, dtype=torch.complex64, device="cuda")
+    rsrc = rpool[shift: shift + n_sym * (n + cp)].view(n_sym, n + cp)
+    rsrc.copy_(tx)
+    rc, rref = oracle.ofdm_rx(ref, n, cp)
+    assert same(ctx.ofdm_rx(rsrc, n, cp).cpu().numpy(), rref)
+
+
 # ---- modulation -------------------------------------------------------------------------------
 @pytest.mark.parametrize("bps", [1, 2, 4, 6, 8, 10])
 def test_to_from_constl_bit_exact(ctx, oracle, bps):
