@@ -432,15 +432,17 @@ struct RxShape {
     static constexpr int STG_OFF = STG_ALIAS ? 0 : (DATA_BYTES + TW_BYTES + IDX_BYTES + REF_BYTES + 15) & ~15;
     static constexpr int LDS_BYTES = (STG_ALIAS ? DATA_BYTES + TW_BYTES + IDX_BYTES + REF_BYTES : STG_OFF + STG_BYTES) + 16;
 
-    // N = 2048 / 4096 with taps: requested per symbol between the barriers of the second exchange
-    // (they land during the last pass) instead of being held across a run of symbols -- 48 fewer
-    // live registers, three waves per SIMD instead of two.
+    // Alternative to holding the taps across a run of two symbols, OFF by default (measured within
+    // a point of it at N = 2048 / 4096, worse at N = 1024): requested per symbol ahead of an exchange
+    // barrier (SDR_LATE_AT: 0 = first exchange, 1 = second) -- 48 fewer live registers, three waves
+    // per SIMD instead of two, but twice the tap traffic through L2.
     static constexpr bool LATE_TAPS = EQ && DEMAP && O::kPasses == 3 && (FULL ? SDR_LATE_TAPS_FULL : (SDR_LATE_TAPS && LOG2N >= 11 && LOG2N <= 12));
     // Only the tap-holding instantiations take a run of symbol groups per workgroup (taps reloaded
     // once per run).  The others take exactly one group and are straight-line code: nothing is
     // hoisted out of a loop into registers (N = 1024 LLR variant: 136 -> 104-119 registers; hard bits
     // beside LLRs: 63 -> 68 %; N = 8192: 56 -> 71 %).  Counting variants then end every symbol with
     // four atomics per wave on the 1024 counter slots, which measured no slower than runs of eight.
+    // (The name is historical: the run of two is written out, see `process` in the kernel.)
     static constexpr bool LOOP = EQ && !LATE_TAPS;
 
     // Waves per SIMD.  Lower bound = register budget: the tap-holding and FULL variants must not
