@@ -122,9 +122,9 @@ struct TxShape {
     // tail stored a second time); the generator assembles the symbol in LDS (rolled noise loops)
     static constexpr bool DIRECT = SDR_TX_DIRECT && SRC_GLOBAL && !NOISE && SPW == 1;      // several symbols per wave: the LDS-assembled rows store better (N = 64: 5.2e9 against 4.5e9 symbols/s)
     static constexpr int LDS_BYTES = TIME_OFF + (DIRECT ? 0 : N * 8 * SPW) + 16;
-    // the plain batched ofdm::tx takes one symbol group per workgroup as straight-line code; the
-    // generator (Philox + Box-Muller, ALU bound) keeps its runs of two
-    static constexpr bool LOOP = !(SDR_TX_STRAIGHT && SRC_GLOBAL);
+    // one symbol group per workgroup as straight-line code (batched ofdm::tx: +20 % at N = 4096; the
+    // ALU-bound generator: +2 to +7 % over runs of two)
+    static constexpr bool LOOP = !SDR_TX_STRAIGHT;
     // two waves per SIMD where LDS allows two workgroups (left alone the compiler takes 256 + a few
     // registers), and never more per SIMD than an even spread of what LDS lets the CU hold
     static constexpr int WAVES_PER_WG = O::kWG / 64;
