@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""bench.py -- throughput of the fused receive path (CP removal -> FFT -> equalise -> max-log LLR).
+"""bench.py -- throughput of the fused receive path (CP removal -> FFT -> [equalise ->] max-log LLR).
 
 A "step" is one pass of the hot path over one batch of synthetic OFDM symbols that is already
 resident in HBM (generated on the device by the library's own frame generator + AWGN).
@@ -25,7 +25,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB
 WORKLOADS = {
     # name: (n_fft, cp, bits/subcarrier, symbols per GPU, Eb/N0 dB, per-subcarrier equaliser)
     "fft1024_16qam_1M": (1024, 256, 4, 1 << 20, 12.0, False),      # configs[1] -- the bench line
-    "fft1024_64qam_1M": (1024, 256, 6, 1 << 20, 16.0, False),      # north_star headline target (>= 70 % HBM)
+    "fft1024_64qam_1M": (1024, 256, 6, 1 << 20, 16.0, False),      # north_star target shape without taps
+    "fft1024_64qam_eq": (1024, 256, 6, 1 << 20, 16.0, True),       # north_star target: FFT -> equalise -> LLR, taps + weights per 14-symbol frame
     "fft2048_64qam_eq": (2048, 512, 6, 1 << 18, 18.0, True),       # configs[2] shape, one resident chunk
     "fft4096_256qam": (4096, 1024, 8, 1 << 17, 24.0, False),       # configs[3] shape, per-GPU chunk
     "fft64_qpsk": (64, 16, 2, 1 << 22, 10.0, False),               # configs[0] shape on the GPU
@@ -147,8 +148,13 @@ def time_workload(ctx, torch, dist, name, steps, warmup, world, rank, n_sym_over
     avg_launch_s = sum(launch_ms) / len(launch_ms) / 1e3
     b_sym = algorithmic_bytes_per_symbol(n_fft, bps)
     achieved = b_sym * n_sym / avg_launch_s / 1e9
+    # Taps (8 B) and weights (4 B) per bin are read from HBM once per set of `per` symbols.  SURVEY.md
+    # 8(d) leaves them out of the algorithmic count ("amortised / L2-resident"), so `frac` does too;
+    # the bytes are real (2.7 % at 14 symbols per set) and are reported beside it.
+    tap_bytes_sym = (12.0 * n_fft / per) if with_eq else 0.0
     res = {
-        "n_fft": n_fft, "cp": cp, "bps": bps, "n_sym": n_sym, "elapsed": elapsed,
+        "n_fft": n_fft, "cp": cp, "bps": bps, "n_sym": n_sym, "elapsed": elapsed, "with_eq": with_eq,
+        "tap_bytes_per_symbol": tap_bytes_sym, "frac_incl_taps": (b_sym + tap_bytes_sym) * n_sym / avg_launch_s / 1e9 / HBM_PEAK_GBS,
         "sym_per_s": world * n_sym * steps / elapsed,
         "copy_shape_gbs": copy_gbs,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -202,12 +208,17 @@ def main():
     if world == 1 and not args.no_extra and args.workload == "fft1024_16qam_1M" and not args.symbols:
         r = time_workload(ctx, torch, dist, "fft1024_64qam_1M", max(3, args.steps // 2), 5, 1, 0)
         extra["fft1024_64qam_1M"] = {"sym_per_s": r["sym_per_s"], "llr_gbit_per_s": r["sym_per_s"] * r["n_fft"] * r["bps"] / 1e9,
-                                     "hbm_frac": r["roofline"]["frac"], "achieved_GBs": r["roofline"]["achieved"]}
-        # the other configurations of BASELINE.json's list, for the record (not bench lines)
-        for name in ("fft2048_64qam_eq", "fft4096_256qam", "fft64_qpsk"):
+                                     "hbm_frac": r["roofline"]["frac"], "achieved_GBs": r["roofline"]["achieved"], "equaliser": False}
+        # the north_star target shape with the equaliser ACTIVE, and the other configurations of
+        # BASELINE.json's list, for the record (not bench lines)
+        for name in ("fft1024_64qam_eq", "fft2048_64qam_eq", "fft4096_256qam", "fft64_qpsk"):
             r = time_workload(ctx, torch, dist, name, max(3, args.steps // 2), 5, 1, 0)
             extra[name] = {"sym_per_s": r["sym_per_s"], "llr_gbit_per_s": r["sym_per_s"] * r["n_fft"] * r["bps"] / 1e9,
-                           "hbm_frac": r["roofline"]["frac"], "achieved_GBs": r["roofline"]["achieved"], "symbols": r["n_sym"]}
+                           "hbm_frac": r["roofline"]["frac"], "achieved_GBs": r["roofline"]["achieved"], "symbols": r["n_sym"],
+                           "equaliser": r["with_eq"]}
+            if r["with_eq"]:
+                extra[name]["hbm_frac_incl_tap_bytes"] = r["frac_incl_taps"]
+                extra[name]["tap_bytes_per_symbol"] = r["tap_bytes_per_symbol"]
     if main_res.get("copy_shape_gbs"):
         extra["copy_of_same_shape"] = {"achieved_GBs": main_res["copy_shape_gbs"], "kernel_over_copy": main_res["roofline"]["achieved"] / main_res["copy_shape_gbs"],
                                        "what": "sdr_diag_copy_shape_c32: the kernel's bytes and access pattern with no arithmetic, same buffers"}
@@ -221,7 +232,8 @@ def main():
     if rank == 0:
         n_fft, bps = main_res["n_fft"], main_res["bps"]
         line = {
-            "metric": "demodulated OFDM symbols/s (fused CP-removal + FFT + equalise + max-log LLR)",
+            "metric": "demodulated OFDM symbols/s (fused CP-removal + FFT + " + ("equalise + " if main_res["with_eq"] else "") + "max-log LLR"
+                      + ("" if main_res["with_eq"] else "; no equaliser in this workload, see extra.fft1024_64qam_eq") + ")",
             "value": main_res["sym_per_s"],
             "unit": "OFDM symbols/s",
             "n_gpus": world,

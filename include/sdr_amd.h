@@ -83,7 +83,9 @@ int sdr_twiddle_table_c64(size_t n, int inverse, double* h_out);
 /* ---- R1/R5: ofdm::rx / ofdm::tx (lib/inc/ofdm.hpp:37-43, :13-24), batched ------------------
  * rx: in = n_sym x (n_fft+cp) samples, out = n_sym x n_fft bins (CP skipped on load).
  * tx: in = n_sym x n_fft bins, out = n_sym x (n_fft+cp) samples (CP = copy of the tail).
- * cp > n_fft is allowed for tx only as in the reference; rx needs n_fft >= 1. */
+ * The batched C ABI requires cp <= n_fft for tx (SDR_ERR_INVALID otherwise); the reference's
+ * sequence for cp > n (lib/inc/ofdm.hpp:16-21 copies past the payload) is kept only by the
+ * one-symbol drop-in ofdm::tx in include/sdrlib/ofdm.hpp.  rx accepts any cp. */
 int sdr_ofdm_rx_c32(sdr_ctx* ctx, const void* d_in, size_t n_fft, size_t cp, size_t n_sym, void* d_out);
 int sdr_ofdm_rx_c64(sdr_ctx* ctx, const void* d_in, size_t n_fft, size_t cp, size_t n_sym, void* d_out);
 int sdr_ofdm_tx_c32(sdr_ctx* ctx, const void* d_in, size_t n_fft, size_t cp, size_t n_sym, void* d_out);
@@ -153,14 +155,11 @@ typedef struct sdr_demod_args {
 } sdr_demod_args;
 int sdr_ofdm_demod_c32(sdr_ctx* ctx, const sdr_demod_args* args);
 /* Same with every pointer in HOST memory (copies in, runs, copies out, synchronises);
- * n_sets = number of tap / weight sets behind d_eq / d_llr_weight (ignored when both are NULL). */
+ * n_sets = number of tap / weight sets behind d_eq / d_llr_weight (ignored when both are NULL).
+ * The kernel indexes set sym / sym_per_set, so n_sets must be at least
+ * ceil(n_sym / sym_per_set) (1 when sym_per_set is 0): fewer is SDR_ERR_INVALID.  The device form
+ * above cannot see the size of its arrays: there the same bound is the caller's contract. */
 int sdr_ofdm_demod_host_c32(sdr_ctx* ctx, const sdr_demod_args* host_args, size_t n_sets);
-
-/* Diagnostic (no reference counterpart, no arithmetic): moves exactly the bytes of
- * sdr_ofdm_demod_c32 with LLR output only -- reads the n_sym*n_fft payload samples, writes
- * n_sym*n_fft*mod floats (values unspecified) -- with the same access pattern, so that a
- * benchmark can quote the receive kernel against the memory system's rate for its shape. */
-int sdr_diag_copy_shape_c32(sdr_ctx* ctx, const void* d_rx, uint32_t n_fft, uint32_t cp, uint32_t mod, uint64_t n_sym, float* d_llr);
 
 /* Equaliser taps and LLR weights from a channel estimate H (n values):
  *   p = |H|^2, G = conj(H)/p, w = norm^2 * p * inv_n0. */
@@ -227,6 +226,9 @@ typedef struct sdr_pipe_config {
     float llr_weight0;
     const void* d_eq;           /* device, n_sets*n_fft c32 or NULL; must outlive the pipe */
     const float* d_llr_weight;  /* device, n_sets*n_fft or NULL */
+    /* The pipe's streams are non-blocking: whatever produced d_eq / d_llr_weight on the device (e.g.
+     * sdr_zf_taps_c32 on another stream) must be COMPLETE before the first sdr_pipe_submit --
+     * synchronise that stream first; nothing in the pipe orders its kernels after it. */
 } sdr_pipe_config;
 typedef struct sdr_pipe_result {
     uint64_t sequence;          /* 0,1,2,... in submission order */

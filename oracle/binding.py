@@ -13,7 +13,7 @@ from ctypes import c_float, c_int, c_size_t, c_uint32, c_uint64, c_void_p, c_lon
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsdr_oracle.so")
+LIB_PATH = os.environ.get("SDR_ORACLE_LIB") or os.path.join(_HERE, "libsdr_oracle.so")   # SDR_ORACLE_LIB: the sanitizer build
 POW2_MESSAGE = "The sequence size must be of powers of 2"
 
 _lib = None

@@ -98,7 +98,7 @@ class PipeResult(Structure):
 
 PIPE_LLR_TO_HOST, PIPE_HARD_TO_HOST, PIPE_WANT_LLR, PIPE_WANT_HARD = 1, 2, 4, 8
 
-# name -> (restype, argtypes); every symbol include/sdr_amd.h declares
+# name -> (restype, argtypes); every symbol include/sdr_amd.h and include/sdr_amd_diag.h declare
 SIGNATURES = {
     "sdr_version": (c_char_p, []),
     "sdr_last_error": (c_char_p, []),

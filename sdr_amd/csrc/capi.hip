@@ -1,6 +1,7 @@
 // capi.hip -- the extern "C" surface declared in include/sdr_amd.h: argument checks, choice
 // between the tuned fused kernels and the generic engines, host-memory convenience forms.
 #include "common.hpp"
+#include "sdr_amd_diag.h"
 #include "kernels.hpp"
 #include "qam.hpp"
 #include "rng.hpp"
@@ -239,29 +240,24 @@ int sdr_soft_demap_c32(sdr_ctx* ctx, int mod, const void* d_sym, size_t n_sym, c
     return soft_demap_dev(ctx, mod, d_sym, n_sym, d_weight, weight0, d_llr);
 }
 
-// host-memory forms: explicit device scratch (hipMalloc/hipFree per call -- convenience path)
-namespace {
-struct DevBuf {
-    void* p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    int alloc(size_t bytes) { if (!bytes) return SDR_OK; hipError_t e = hipMalloc(&p, bytes); return e == hipSuccess ? SDR_OK : fail_hip(e, "hipMalloc(host-form scratch)"); }
-};
-}
-
 int sdr_soft_demap_host_c32(sdr_ctx* ctx, int mod, const void* h_sym, size_t n_sym, const float* h_weight, float weight0, float* h_llr)
 {
     SDR_TRY(ensure_device(ctx));
     if (!valid_mod(mod)) return fail(SDR_ERR_INVALID, "unknown modulation %d", mod);
     if (n_sym == 0) return SDR_OK;
     if (!h_sym || !h_llr) return fail(SDR_ERR_INVALID, "null host pointer");
-    DevBuf sym, w, out;
-    SDR_TRY(sym.alloc(n_sym * 8));
-    SDR_TRY(out.alloc(n_sym * mod * 4));
-    if (h_weight) SDR_TRY(w.alloc(n_sym * 4));
-    SDR_HIP(hipMemcpyAsync(sym.p, h_sym, n_sym * 8, hipMemcpyHostToDevice, ctx->stream));
-    if (h_weight) SDR_HIP(hipMemcpyAsync(w.p, h_weight, n_sym * 4, hipMemcpyHostToDevice, ctx->stream));
-    SDR_TRY(soft_demap_dev(ctx, mod, sym.p, n_sym, static_cast<const float*>(w.p), weight0, static_cast<float*>(out.p)));
-    SDR_HIP(hipMemcpyAsync(h_llr, out.p, n_sym * mod * 4, hipMemcpyDeviceToHost, ctx->stream));
+    // one arena from the context's staging (kept for the next call), like sdr_ofdm_demod_host_c32
+    auto up = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
+    const size_t o_w = up(n_sym * 8);
+    const size_t o_out = o_w + (h_weight ? up(n_sym * 4) : 0);
+    void* arena_v = nullptr;
+    SDR_TRY(get_staging(ctx, 3, o_out + up(n_sym * mod * 4), &arena_v));
+    unsigned char* arena = static_cast<unsigned char*>(arena_v);
+    float* d_w = h_weight ? reinterpret_cast<float*>(arena + o_w) : nullptr;
+    SDR_HIP(hipMemcpyAsync(arena, h_sym, n_sym * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (h_weight) SDR_HIP(hipMemcpyAsync(d_w, h_weight, n_sym * 4, hipMemcpyHostToDevice, ctx->stream));
+    SDR_TRY(soft_demap_dev(ctx, mod, arena, n_sym, d_w, weight0, reinterpret_cast<float*>(arena + o_out)));
+    SDR_HIP(hipMemcpyAsync(h_llr, arena + o_out, n_sym * mod * 4, hipMemcpyDeviceToHost, ctx->stream));
     SDR_HIP(hipStreamSynchronize(ctx->stream));
     return SDR_OK;
 }
@@ -281,6 +277,12 @@ int sdr_ofdm_demod_host_c32(sdr_ctx* ctx, const sdr_demod_args* host_args, size_
     const size_t hard_bytes = bins * a.mod / 8;
     // one arena from the context's staging (grown on demand, kept for the next call) instead of
     // eight hipMalloc / hipFree pairs per call
+    // the kernel indexes tap set sym / sym_per_set (set 0 alone when sym_per_set is 0): every set it
+    // can reach must be behind the host pointers, or it would read the neighbouring arena regions
+    const size_t need_sets = a.sym_per_set ? static_cast<size_t>((a.n_sym + a.sym_per_set - 1) / a.sym_per_set) : 1;
+    if ((a.d_eq || a.d_llr_weight) && n_sets < need_sets)
+        return fail(SDR_ERR_INVALID, "n_sets = %zu but %llu symbols with sym_per_set = %u index %zu tap / weight sets", n_sets,
+                    static_cast<unsigned long long>(a.n_sym), a.sym_per_set, need_sets);
     const size_t set_bytes = n_sets * a.n_fft;
     auto up = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
     const size_t o_rx = 0;

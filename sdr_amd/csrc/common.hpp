@@ -68,6 +68,8 @@ constexpr int kCounterSlots = 1024;
 int get_counter_slots(sdr_ctx* ctx, unsigned long long** slots);
 // adds the slots and the counts that need no measuring (bits, symbols, OFDM symbols) into d_counters
 int fold_counters(sdr_ctx* ctx, unsigned long long* d_counters, uint64_t n_points, uint32_t bps, uint64_t n_ofdm);
+// the same on a caller-provided slot array (no allocation)
+int fold_counter_slots(sdr_ctx* ctx, unsigned long long* slots, unsigned long long* d_counters, uint64_t n_points, uint32_t bps, uint64_t n_ofdm);
 
 // Host-side generation of the reference's per-stage twiddle sequence (lib/inc/fft.hpp:113-150).
 void make_twiddles_f32(size_t n, bool inverse, float* out);

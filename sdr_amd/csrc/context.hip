@@ -1,5 +1,6 @@
 // context.hip -- context lifetime, thread-local error text, twiddle-table cache, staging buffers.
 #include "common.hpp"
+#include "kernels.hpp"
 
 #include <cmath>
 #include <cstring>
@@ -167,6 +168,11 @@ int fold_counters(sdr_ctx* ctx, unsigned long long* d_counters, uint64_t n_point
 {
     unsigned long long* slots = nullptr;
     SDR_TRY(get_counter_slots(ctx, &slots));
+    return fold_counter_slots(ctx, slots, d_counters, n_points, bps, n_ofdm);
+}
+
+int fold_counter_slots(sdr_ctx* ctx, unsigned long long* slots, unsigned long long* d_counters, uint64_t n_points, uint32_t bps, uint64_t n_ofdm)
+{
     hipLaunchKernelGGL(fold_counters_kernel, dim3(1), dim3(kCounterSlots), 0, ctx->stream, slots, d_counters,
                        static_cast<unsigned long long>(n_points), bps, static_cast<unsigned long long>(n_ofdm));
     hipError_t e = hipGetLastError();

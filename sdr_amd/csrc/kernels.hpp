@@ -23,7 +23,13 @@ int demap_after_fft(sdr_ctx* ctx, const sdr_demod_args& a, const void* d_fft);
 // rx_fused.hip: the tuned fused receive kernel (fp32, n_fft 64..4096).
 bool rx_fused_supported(uint32_t n_fft, uint32_t mod);
 bool rx_fused_layout_ok(const sdr_demod_args& a);
-int rx_fused_launch(sdr_ctx* ctx, const sdr_demod_args& a);
+// Device memory the launch needs beyond inputs and outputs.  Null members are taken from the
+// context's own (allocating) caches; the allocation-free entry point brings its static array.
+struct RxWorkspace {
+    const void* twiddles = nullptr;          // n_fft - 1 forward twiddles
+    unsigned long long* counter_slots = nullptr;   // kCounterSlots x 8, all zero
+};
+int rx_fused_launch(sdr_ctx* ctx, const sdr_demod_args& a, const RxWorkspace* ws = nullptr);
 int rx_fft_only_launch(sdr_ctx* ctx, const void* d_in, uint32_t n_fft, uint32_t cp, uint64_t n_sym, void* d_out);
 int copy_shape_launch(sdr_ctx* ctx, const void* d_rx, uint32_t n_fft, uint32_t cp, uint32_t bps, uint64_t n_sym, float* d_out);
 

@@ -56,10 +56,10 @@ bool rx_fused_layout_ok(const sdr_demod_args& a)
     return true;
 }
 
-int rx_fused_launch(sdr_ctx* ctx, const sdr_demod_args& a)
+int rx_fused_launch(sdr_ctx* ctx, const sdr_demod_args& a, const RxWorkspace* ws)
 {
-    const void* tw = nullptr;
-    SDR_TRY(get_twiddles(ctx, a.n_fft, false, false, &tw));
+    const void* tw = ws ? ws->twiddles : nullptr;
+    if (!tw) SDR_TRY(get_twiddles(ctx, a.n_fft, false, false, &tw));
     RxParams p = {};
     p.rx = static_cast<const float2*>(a.d_rx);
     p.tw = static_cast<const float2*>(tw);
@@ -69,7 +69,10 @@ int rx_fused_launch(sdr_ctx* ctx, const sdr_demod_args& a)
     p.hard = a.d_hard;
     p.fft = static_cast<float2*>(a.d_fft);
     p.ref = a.d_ref_hard;
-    if (a.d_counters) SDR_TRY(get_counter_slots(ctx, &p.counters));
+    if (a.d_counters) {
+        if (ws && ws->counter_slots) p.counters = ws->counter_slots;
+        else SDR_TRY(get_counter_slots(ctx, &p.counters));
+    }
     p.n_sym = a.n_sym;
     p.cp = a.cp;
     p.sym_per_set = a.sym_per_set;
@@ -79,7 +82,7 @@ int rx_fused_launch(sdr_ctx* ctx, const sdr_demod_args& a)
     const bool hard_only = a.d_hard && !a.d_llr && !a.d_fft && !a.d_counters && !a.d_eq && a.mod != 1;   // weights do not matter to nearest()
     const int variant = hard_only ? 4 : (full ? 2 : 0) | ((a.d_eq || a.d_llr_weight) ? 1 : 0);
     SDR_TRY(dispatch(ctx, ilog2(a.n_fft), p, static_cast<int>(a.mod), variant));
-    if (a.d_counters) SDR_TRY(fold_counters(ctx, reinterpret_cast<unsigned long long*>(a.d_counters), a.n_sym * a.n_fft, a.mod, a.n_sym));
+    if (a.d_counters) SDR_TRY(fold_counter_slots(ctx, p.counters, reinterpret_cast<unsigned long long*>(a.d_counters), a.n_sym * a.n_fft, a.mod, a.n_sym));
     return SDR_OK;
 }
 

@@ -93,6 +93,8 @@ class Context:
 
     # ---- ofdm::rx / ofdm::tx (lib/inc/ofdm.hpp:13-54), batched ----
     def ofdm_rx(self, rx: torch.Tensor, n_fft: int, cp: int) -> torch.Tensor:
+        if rx.dtype not in (torch.complex64, torch.complex128):
+            raise ValueError("ofdm_rx needs a complex tensor")
         _need(rx, rx.dtype, "rx")
         n_sym = rx.numel() // (n_fft + cp) if (n_fft + cp) else 0
         if rx.numel() != n_sym * (n_fft + cp):
@@ -103,8 +105,12 @@ class Context:
         return out
 
     def ofdm_tx(self, freq: torch.Tensor, n_fft: int, cp: int) -> torch.Tensor:
+        if freq.dtype not in (torch.complex64, torch.complex128):
+            raise ValueError("ofdm_tx needs a complex tensor")
         _need(freq, freq.dtype, "freq")
         n_sym = freq.numel() // n_fft if n_fft else 0
+        if freq.numel() != n_sym * n_fft:
+            raise ValueError("freq length is not a multiple of n_fft")
         out = torch.empty((n_sym, n_fft + cp), dtype=freq.dtype, device=freq.device)
         fn = self.lib.sdr_ofdm_tx_c32 if freq.dtype == torch.complex64 else self.lib.sdr_ofdm_tx_c64
         check(fn(self._h, _ptr(freq), n_fft, cp, n_sym, _ptr(out)))
@@ -184,11 +190,17 @@ class Context:
         a.sym_per_set = sym_per_set
         a.llr_weight0 = 0.0 if wt is not None else float(llr_weight)
         a.d_rx = rx.data_ptr()
+        # the kernel indexes tap set sym // sym_per_set (set 0 alone when sym_per_set is 0)
+        need = n_fft * ((n_sym + sym_per_set - 1) // sym_per_set if sym_per_set else 1)
         if eq is not None:
             _need(eq, torch.complex64, "eq")
+            if eq.numel() < need:
+                raise ValueError(f"eq must hold at least {need} taps ({need // max(n_fft, 1)} sets of {n_fft}), got {eq.numel()}")
             a.d_eq = eq.data_ptr()
         if wt is not None:
             _need(wt, torch.float32, "llr_weight")
+            if wt.numel() < need:
+                raise ValueError(f"llr_weight must hold at least {need} weights ({need // max(n_fft, 1)} sets of {n_fft}), got {wt.numel()}")
             a.d_llr_weight = wt.data_ptr()
         if llr is not None:
             _need(llr, torch.float32, "llr", n_sym * n_fft * bps)

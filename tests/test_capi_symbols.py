@@ -1,5 +1,5 @@
 """CPU-only checks of the C ABI: the shared library loads, exports every symbol that
-include/sdr_amd.h declares, and its host-side pieces (twiddle generator, constellation tables,
+include/sdr_amd.h and include/sdr_amd_diag.h declare, and its host-side pieces (twiddle generator, constellation tables,
 Philox, error text) agree with the oracle.  No GPU compute is called here."""
 import ctypes
 import os
@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "sdr_amd.h")).read()
+    text = "".join(open(os.path.join(ROOT, "include", h)).read() for h in ("sdr_amd.h", "sdr_amd_diag.h"))
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(sdr_[a-z0-9_]+)\s*\(", text)))
 

@@ -120,20 +120,22 @@ def test_fft2_golden(ctx):
 # ---- ofdm::rx / tx batched -------------------------------------------------------------------
 @pytest.mark.parametrize("n,cp", [(8, 8), (64, 16), (256, 64), (1024, 256), (2048, 512), (4096, 1024), (128, 0), (512, 37), (128, 32), (512, 128),
                                   (16, 4), (8192, 2048), (1024, 1024), (1024, 37), (2048, 1), (8192, 3), (4096, 5)])
-def test_ofdm_rx_tx_bit_exact(ctx, oracle, n, cp):
+@pytest.mark.parametrize("dt", [np.complex64, np.complex128])
+def test_ofdm_rx_tx_bit_exact(ctx, oracle, n, cp, dt):
+    """fp32 and fp64 (fft_test.cpp:12-22 and ofdm_test.cpp:13-25 run the reference in double)."""
     rng = np.random.default_rng(n + cp)
     s = 7
-    rx = rand_c(rng, (s, n + cp))
+    rx = rand_c(rng, (s, n + cp), dt)
     rc, ref = oracle.ofdm_rx(rx, n, cp)
     got = ctx.ofdm_rx(dev(rx), n, cp).cpu().numpy()
     assert same(got, ref), rel_err(got, ref)
-    fr = rand_c(rng, (s, n))
+    fr = rand_c(rng, (s, n), dt)
     rc, ref = oracle.ofdm_tx(fr, n, cp)
     got = ctx.ofdm_tx(dev(fr), n, cp).cpu().numpy()
-    assert same(got, ref), rel_err(got, ref)
+    assert got.dtype == dt and same(got, ref), rel_err(got, ref)
     # round trip property at any size
     back = ctx.ofdm_rx(ctx.ofdm_tx(dev(fr), n, cp), n, cp).cpu().numpy()
-    assert rel_err(back, fr) < 1e-5
+    assert rel_err(back, fr) < (1e-5 if dt == np.complex64 else 1e-13)
 
 
 def _random_tx_cases(count=32, seed=4242):
@@ -142,20 +144,23 @@ def _random_tx_cases(count=32, seed=4242):
             for i in range(count)]
 
 
+@pytest.mark.parametrize("dt", [np.complex64, np.complex128])
 @pytest.mark.parametrize("i,n,n_sym,shift", _random_tx_cases())
-def test_ofdm_tx_rx_random_layouts(ctx, oracle, i, n, n_sym, shift):
+def test_ofdm_tx_rx_random_layouts(ctx, oracle, i, n, n_sym, shift, dt):
     """Batched ofdm::tx / ofdm::rx with random prefix lengths (odd ones included), batch sizes and
-    buffers that start 0, 8 or 16 bytes into an allocation: every dispatch path equals the oracle."""
+    buffers that start 0, 1 or 2 elements into an allocation: every dispatch path equals the oracle,
+    in fp32 and in fp64."""
     rng = np.random.default_rng(500 + i)
     cp = int(rng.integers(0, n + 1))
-    fr = rand_c(rng, (n_sym, n))
-    pool = torch.empty(n_sym * n + 4, dtype=torch.complex64, device="cuda")
+    fr = rand_c(rng, (n_sym, n), dt)
+    tdt = torch.complex64 if dt == np.complex64 else torch.complex128
+    pool = torch.empty(n_sym * n + 4, dtype=tdt, device="cuda")
     src = pool[shift: shift + n_sym * n].view(n_sym, n)
     src.copy_(dev(fr))
     rc, ref = oracle.ofdm_tx(fr, n, cp)
     tx = ctx.ofdm_tx(src, n, cp)
     assert same(tx.cpu().numpy(), ref)
-    rpool = torch.empty(n_sym * (n + cp) + 4, dtype=torch.complex64, device="cuda")
+    rpool = torch.empty(n_sym * (n + cp) + 4, dtype=tdt, device="cuda")
     rsrc = rpool[shift: shift + n_sym * (n + cp)].view(n_sym, n + cp)
     rsrc.copy_(tx)
     rc, rref = oracle.ofdm_rx(ref, n, cp)
@@ -681,6 +686,23 @@ def test_c_abi_argument_errors(ctx):
     assert lib.sdr_ofdm_demod_c32(h, ctypes.byref(args(d_counters=cnt.data_ptr()))) == capi.SDR_ERR_INVALID   # counters without reference bits
     assert lib.sdr_ofdm_demod_c32(h, ctypes.byref(args(n_sym=0))) == capi.SDR_OK                                # empty batch: nothing to do
     torch.cuda.synchronize()
+    # host form: too few tap / weight sets for what the kernel would index is refused, not read out of bounds
+    h_rx = np.zeros(30 * 80, dtype=np.complex64)
+    h_llr = np.zeros(30 * 64 * 4, dtype=np.float32)
+    h_eq = np.ones(2 * 64, dtype=np.complex64)
+    h_w = np.ones(2 * 64, dtype=np.float32)
+    hp = lambda a_: a_.ctypes.data_as(ctypes.c_void_p).value
+    host = lambda **kw: args(n_sym=30, sym_per_set=14, d_rx=hp(h_rx), d_llr=hp(h_llr), **kw)
+    assert lib.sdr_ofdm_demod_host_c32(h, ctypes.byref(host(d_eq=hp(h_eq))), 2) == capi.SDR_ERR_INVALID       # 30 symbols / 14 = 3 sets
+    assert "n_sets" in capi.last_error()
+    assert lib.sdr_ofdm_demod_host_c32(h, ctypes.byref(host(d_llr_weight=hp(h_w))), 0) == capi.SDR_ERR_INVALID
+    assert lib.sdr_ofdm_demod_host_c32(h, ctypes.byref(host(d_eq=hp(h_eq), sym_per_set=0)), 0) == capi.SDR_ERR_INVALID   # one set needed
+    assert lib.sdr_ofdm_demod_host_c32(h, ctypes.byref(host(d_eq=hp(h_eq), sym_per_set=15)), 2) == capi.SDR_OK
+    assert lib.sdr_ofdm_demod_host_c32(h, ctypes.byref(host()), 0) == capi.SDR_OK                              # no taps: n_sets ignored
+    with pytest.raises(ValueError):
+        ctx.demod(rx, 64, 16, 4, eq=torch.ones(64, dtype=torch.complex64, device="cuda"), sym_per_set=2)        # 4 symbols / 2 = 2 sets needed
+    with pytest.raises(ValueError):
+        ctx.demod(rx, 64, 16, 4, llr_weight=torch.ones(63, dtype=torch.float32, device="cuda"))
 
 
 def test_two_contexts_in_two_threads(oracle):

@@ -5,7 +5,8 @@
 
 case = n_fft:bps[:eq][:hard][:cnt]   (bps 0 = FFT only / ofdm::rx batch; bps 'fft' / 'ifft' = in-place fft::fft2 / ifft2 batch; eq = per-subcarrier
 equaliser sets; hard = also packed hard bits; cnt = error counters against reference bits; nollr = no LLR
-output, i.e. with hard: the reference's own chain ofdm::rx -> from_constl)
+output, i.e. with hard: the reference's own chain ofdm::rx -> from_constl; gen = the frame generator with
+noise, GB/s = samples written; mc = the Monte-Carlo link kernel, GB/s = what the receive kernel would move)
 Inputs are random complex noise (values do not change the instruction stream).
 """
 import argparse
@@ -58,7 +59,21 @@ def main():
         no_llr = "nollr" in parts[2:]
         if no_llr:
             bytes_sym -= 4 * n * bps
-        if bps:
+        if "gen" in parts[2:] or "mc" in parts[2:]:
+            # frame generator with noise (bytes = samples written) / Monte-Carlo link (no HBM traffic: reported as LLR-equivalent bytes)
+            del rx
+            rx = None
+            if "gen" in parts[2:]:
+                n_sym = args.symbols or min(1 << 18, (4 << 30) // ((n + cp) * 8))
+                gout = torch.empty((n_sym, n + cp), dtype=torch.complex64, device="cuda")
+                bytes_sym = (n + cp) * 8
+                step = lambda: ctx.link_generate(n, cp, bps, 1, 0, n_sym, 0.01, out_rx=gout, want_bits=False)
+            else:
+                n_sym = args.symbols or (1 << 18)
+                mcnt = torch.zeros(8, dtype=torch.int64, device="cuda")
+                bytes_sym = 8 * n + 4 * n * bps
+                step = lambda: ctx.link_ber(n, cp, bps, 1, 0, n_sym, 0.01, 1.0, counters=mcnt)
+        elif bps:
             out = None if no_llr else torch.empty((n_sym, n, bps), dtype=torch.float32, device="cuda")
             step = lambda: ctx.demod(rx, n, cp, bps, eq=eq, llr_weight=(wgt if wgt is not None else 1.5), sym_per_set=per, out_llr=out, want_llr=not no_llr,
                                      out_hard=hard, ref_hard=ref, counters=cnt)
@@ -86,8 +101,7 @@ def main():
         if args.repeat == 1:
             print(f"case {case:>12s} n_sym {n_sym:8d}  {ms:8.3f} ms/launch  {n_sym / ms / 1e3:9.2f} Msym/s  {gbs:8.1f} GB/s  {gbs / 80:5.1f} % of 8 TB/s", flush=True)
         del rx, eq, wgt, hard, ref, cnt
-        if bps:
-            del out
+        out = gout = mcnt = None
         torch.cuda.empty_cache()
     if args.repeat > 1:
         for case, v in results.items():
