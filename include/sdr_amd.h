@@ -161,6 +161,18 @@ int sdr_ofdm_demod_c32(sdr_ctx* ctx, const sdr_demod_args* args);
  * above cannot see the size of its arrays: there the same bound is the caller's contract. */
 int sdr_ofdm_demod_host_c32(sdr_ctx* ctx, const sdr_demod_args* host_args, size_t n_sets);
 
+/* sdr_ofdm_demod_c32 for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE: it
+ * exists for code that must not call hipMalloc while it runs -- HIP graph capture, tight serving
+ * loops, harnesses that forbid allocation.  Same arguments, same results, but the device memory
+ * the kernels need beyond inputs and outputs (the twiddle table and the 1024 x 8 counter slots,
+ * which sdr_ofdm_demod_c32 allocates lazily in the context) comes from one static device array of
+ * 192 KiB per GPU, resolved and filled once per device by sdr_create.  The call enqueues one
+ * 64 KiB hipMemsetAsync (counting calls only), the receive kernel and the counter fold -- no
+ * hipMalloc, hipFree or copy.  Limits: n_fft = 64 ... 8192, even cp, 16-byte aligned buffers (what
+ * the tuned kernels take); anything else is SDR_ERR_UNSUPPORTED.  Every call on a GPU shares that
+ * GPU's array: calls that overlap in time on ONE GPU (two contexts or streams) race on the slots. */
+int sdr_ofdm_demod_noalloc_c32(sdr_ctx* ctx, const sdr_demod_args* args);
+
 /* Equaliser taps and LLR weights from a channel estimate H (n values):
  *   p = |H|^2, G = conj(H)/p, w = norm^2 * p * inv_n0. */
 int sdr_zf_taps_c32(sdr_ctx* ctx, int mod, const void* d_chan, size_t n, float inv_n0, void* d_taps, float* d_weight);

@@ -137,6 +137,7 @@ SIGNATURES = {
     "sdr_constellation_f32": (c_int, [c_int, POINTER(c_float), POINTER(c_float), c_void_p]),
     "sdr_ofdm_demod_c32": (c_int, [c_void_p, POINTER(DemodArgs)]),
     "sdr_ofdm_demod_host_c32": (c_int, [c_void_p, POINTER(DemodArgs), c_size_t]),
+    "sdr_ofdm_demod_noalloc_c32": (c_int, [c_void_p, POINTER(DemodArgs)]),
     "sdr_diag_copy_shape_c32": (c_int, [c_void_p, c_void_p, c_uint32, c_uint32, c_uint32, c_uint64, c_void_p]),
     "sdr_zf_taps_c32": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_float, c_void_p, c_void_p]),
     "sdr_soft_demap_c32": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p, c_float, c_void_p]),

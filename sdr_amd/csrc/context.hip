@@ -221,6 +221,8 @@ static int create_common(int device, hipStream_t borrowed, bool borrow, sdr_ctx*
     ctx->num_cu = prop.multiProcessorCount;
     ctx->lds_max = prop.sharedMemPerBlockOptin ? prop.sharedMemPerBlockOptin : prop.sharedMemPerBlock;
     if (ctx->lds_max < prop.sharedMemPerBlock) ctx->lds_max = prop.sharedMemPerBlock;
+    // the allocation-free entry point's static array: address and tables resolved here, once per device
+    if (int rc = noalloc_setup_device(device); rc != SDR_OK) { sdr_destroy(ctx); return rc; }
     *out = ctx;
     return SDR_OK;
 }

@@ -30,6 +30,8 @@ struct RxWorkspace {
     unsigned long long* counter_slots = nullptr;   // kCounterSlots x 8, all zero
 };
 int rx_fused_launch(sdr_ctx* ctx, const sdr_demod_args& a, const RxWorkspace* ws = nullptr);
+// noalloc.hip: resolves the static scratch array of `device` (once per device) -- called by sdr_create
+int noalloc_setup_device(int device);
 int rx_fft_only_launch(sdr_ctx* ctx, const void* d_in, uint32_t n_fft, uint32_t cp, uint64_t n_sym, void* d_out);
 int copy_shape_launch(sdr_ctx* ctx, const void* d_rx, uint32_t n_fft, uint32_t cp, uint32_t bps, uint64_t n_sym, float* d_out);
 

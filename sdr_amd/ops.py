@@ -173,7 +173,9 @@ class Context:
               llr_weight=1.0, sym_per_set: int = 0, want_llr: bool = True, want_hard: bool = False,
               want_fft: bool = False, ref_hard: Optional[torch.Tensor] = None, counters: Optional[torch.Tensor] = None,
               out_llr: Optional[torch.Tensor] = None, out_hard: Optional[torch.Tensor] = None,
-              out_fft: Optional[torch.Tensor] = None) -> DemodResult:
+              out_fft: Optional[torch.Tensor] = None, noalloc: bool = False) -> DemodResult:
+        """noalloc=True calls sdr_ofdm_demod_noalloc_c32 (static device scratch, no hipMalloc in the
+        library; pass every out_* tensor so that torch allocates nothing either)."""
         bps = mod_bits(mod)
         _need(rx, torch.complex64, "rx")
         n_sym = rx.numel() // (n_fft + cp)
@@ -216,7 +218,8 @@ class Context:
             _need(counters, torch.int64, "counters", 8)
             a.d_ref_hard = ref_hard.data_ptr()
             a.d_counters = counters.data_ptr()
-        check(self.lib.sdr_ofdm_demod_c32(self._h, ctypes.byref(a)))
+        fn = self.lib.sdr_ofdm_demod_noalloc_c32 if noalloc else self.lib.sdr_ofdm_demod_c32
+        check(fn(self._h, ctypes.byref(a)))
         return DemodResult(llr, hard, fft)
 
     # ---- device frame generator / AWGN / Monte-Carlo link ----

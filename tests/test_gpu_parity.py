@@ -692,7 +692,7 @@ def test_c_abi_argument_errors(ctx):
     h_eq = np.ones(2 * 64, dtype=np.complex64)
     h_w = np.ones(2 * 64, dtype=np.float32)
     hp = lambda a_: a_.ctypes.data_as(ctypes.c_void_p).value
-    host = lambda **kw: args(n_sym=30, sym_per_set=14, d_rx=hp(h_rx), d_llr=hp(h_llr), **kw)
+    host = lambda **kw: args(**{**dict(n_sym=30, sym_per_set=14, d_rx=hp(h_rx), d_llr=hp(h_llr)), **kw})
     assert lib.sdr_ofdm_demod_host_c32(h, ctypes.byref(host(d_eq=hp(h_eq))), 2) == capi.SDR_ERR_INVALID       # 30 symbols / 14 = 3 sets
     assert "n_sets" in capi.last_error()
     assert lib.sdr_ofdm_demod_host_c32(h, ctypes.byref(host(d_llr_weight=hp(h_w))), 0) == capi.SDR_ERR_INVALID
