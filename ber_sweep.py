@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """ber_sweep.py -- Eb/N0 Monte-Carlo BER sweep on the device (BASELINE.json configs[4]).
 
-Frames are generated, sent through AWGN, demodulated and counted entirely on the GPU
-(sdr_link_ber_c32: nothing but eight counters per point touches HBM).  With N ranks the frame
+Frames are generated, sent through AWGN, demodulated and counted entirely on the GPU, every
+(modulation, Eb/N0) point of the sweep in ONE launch (sdr_link_sweep_c32: nothing but eight counters
+per point touches HBM).  The Gaussian samples come from a 24-bit uniform (sdr_amd/csrc/rng.hpp), so
+|z| <= 5.77 sigma: points with a BER below about 1e-8 would read low; the default sweep stays above.  With N ranks the frame
 range of every (modulation, Eb/N0) point is split over the ranks and ONE all-reduce(sum) of the
 int64 counter vector ends the sweep; random streams are keyed by the global symbol index, so
 the counts are identical for any number of GPUs.
@@ -34,6 +36,7 @@ def main():
     ap.add_argument("--step-db", type=float, default=1.0)
     ap.add_argument("--seed", type=int, default=5)
     ap.add_argument("--repeat", type=int, default=1, help="timed repetitions of the sweep")
+    ap.add_argument("--per-point", action="store_true", help="one sdr_link_ber_c32 launch per point (the round-1 form) instead of one sdr_link_sweep_c32 launch per sweep")
     args = ap.parse_args()
 
     import torch
@@ -70,15 +73,17 @@ def main():
     points = link.plan_sweep(args.mods, ebn0, args.n_fft, args.bits)
     counters = torch.zeros((len(points), 8), dtype=torch.int64, device="cuda")
 
+    # this rank's share of every point: (modulation, sigma, LLR weight, first global symbol, symbols)
+    mine = link.rank_points(points, args.n_fft, rank, world)
+
     def run_once():
         counters.zero_()
-        for i, p in enumerate(points):
-            first, count = link.shard_frames(p.n_frames, rank, world)
-            if count == 0:
-                continue
-            g0 = (p.first_frame + first) * link.SYMBOLS_PER_FRAME
-            ctx.link_ber(args.n_fft, args.cp, p.mod_bits, args.seed, g0, count * link.SYMBOLS_PER_FRAME,
-                         link.noise_sigma(args.n_fft, p.mod_bits, p.ebn0_db), link.llr_weight(p.mod_bits, p.ebn0_db), counters=counters[i])
+        if args.per_point:
+            for i, (mod, sigma, w, g0, n_sym) in enumerate(mine):
+                if n_sym:
+                    ctx.link_ber(args.n_fft, args.cp, mod, args.seed, g0, n_sym, sigma, w, counters=counters[i])
+        else:
+            ctx.link_sweep(args.n_fft, args.cp, args.seed, mine, counters)      # ONE launch for the whole sweep
         if world > 1:
             if dist.get_backend() == "nccl":
                 dist.all_reduce(counters, op=dist.ReduceOp.SUM)  # the only collective: O(KiB) of int64 over RCCL
@@ -116,7 +121,9 @@ def main():
             "n_gpus": world, "seconds_per_sweep": elapsed, "points": len(points), "total_bits": total_bits,
             "config": {"workload": "ebn0_sweep", "n_fft": args.n_fft, "cp": args.cp, "mods": args.mods, "frames": total_frames, "symbols_per_frame": link.SYMBOLS_PER_FRAME},
             "scaling": "strong", "collective": "one all_reduce(SUM) of %d int64" % (len(points) * 8),
+            "launches_per_sweep": (len(points) if args.per_point else 1),
             "checksum_bit_errors": sum(r[0] for r in c),
+            "counters": c,
         }))
     ctx.close()
     if world > 1:

@@ -209,6 +209,31 @@ int sdr_link_generate_c32(sdr_ctx* ctx, const sdr_link_args* args);
 /* generate -> demodulate -> count entirely on the device; nothing but counters touches HBM. */
 int sdr_link_ber_c32(sdr_ctx* ctx, const sdr_link_args* args);
 
+/* A whole Eb/N0 sweep (BASELINE.json configs[4]) as ONE launch: `n_points` (modulation, noise
+ * level) points, each with the symbol range this rank handles, generated -> demodulated ->
+ * counted on the device; row i of d_counters (n_points x 8 uint64, accumulated into) receives
+ * point i.  Same results as one sdr_link_ber_c32 call per point.  `points` is HOST memory (copied
+ * to the device by the call); points with n_sym = 0 are skipped.  Model of the loop:
+ * app/QFDemoWindow.cpp:201-224 (one symbol per tick there). */
+typedef struct sdr_sweep_point {
+    uint32_t mod;               /* sdr_modulation */
+    float sigma;                /* per-component noise standard deviation, time domain */
+    float llr_weight0;
+    uint32_t reserved;
+    uint64_t first_symbol;      /* global index of the first symbol of this point handled here */
+    uint64_t n_sym;
+} sdr_sweep_point;
+typedef struct sdr_sweep_args {
+    uint32_t struct_size;       /* = sizeof(sdr_sweep_args) */
+    uint32_t n_fft;
+    uint32_t cp;
+    uint32_t n_points;
+    uint64_t seed;
+    const sdr_sweep_point* points;   /* host */
+    uint64_t* d_counters;            /* device, n_points x 8 */
+} sdr_sweep_args;
+int sdr_link_sweep_c32(sdr_ctx* ctx, const sdr_sweep_args* args);
+
 /* ---- Streaming ingest ------------------------------------------------
  * What sits in front of the path in the reference is a host-side ring that is fed one OFDM
  * symbol at a time (utils::sliding_buffer, lib/inc/sliding_buffer.hpp:14-104, filled at

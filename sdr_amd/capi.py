@@ -69,6 +69,29 @@ class LinkArgs(Structure):
     ]
 
 
+class SweepPoint(Structure):
+    _fields_ = [
+        ("mod", c_uint32),
+        ("sigma", c_float),
+        ("llr_weight0", c_float),
+        ("reserved", c_uint32),
+        ("first_symbol", c_uint64),
+        ("n_sym", c_uint64),
+    ]
+
+
+class SweepArgs(Structure):
+    _fields_ = [
+        ("struct_size", c_uint32),
+        ("n_fft", c_uint32),
+        ("cp", c_uint32),
+        ("n_points", c_uint32),
+        ("seed", c_uint64),
+        ("points", POINTER(SweepPoint)),
+        ("d_counters", c_void_p),
+    ]
+
+
 class PipeConfig(Structure):
     _fields_ = [
         ("struct_size", c_uint32),
@@ -144,6 +167,7 @@ SIGNATURES = {
     "sdr_soft_demap_host_c32": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p, c_float, c_void_p]),
     "sdr_link_generate_c32": (c_int, [c_void_p, POINTER(LinkArgs)]),
     "sdr_link_ber_c32": (c_int, [c_void_p, POINTER(LinkArgs)]),
+    "sdr_link_sweep_c32": (c_int, [c_void_p, POINTER(SweepArgs)]),
     "sdr_philox4x32_10": (c_int, [POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32)]),
     "sdr_pipe_create": (c_int, [c_int, POINTER(PipeConfig), POINTER(c_void_p)]),
     "sdr_pipe_acquire": (c_int, [c_void_p, POINTER(c_void_p)]),

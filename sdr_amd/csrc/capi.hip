@@ -330,6 +330,13 @@ int sdr_link_ber_c32(sdr_ctx* ctx, const sdr_link_args* args)
     return link_ber(ctx, *args);
 }
 
+int sdr_link_sweep_c32(sdr_ctx* ctx, const sdr_sweep_args* args)
+{
+    SDR_TRY(ensure_device(ctx));
+    if (!args) return fail(SDR_ERR_INVALID, "null args");
+    return link_sweep(ctx, *args);
+}
+
 int sdr_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
 {
     if (!ctr || !key || !out) return fail(SDR_ERR_INVALID, "null pointer");

@@ -52,7 +52,12 @@ struct sdr_ctx {
     size_t lds_max = 0;   // bytes of LDS one workgroup may use
     // key: (n, inverse, is_double) -> device table of n-1 complex twiddles
     std::map<std::tuple<size_t, int, int>, void*> twiddles;
-    sdr::Staging stage[8];
+    sdr::Staging stage[10];
+    // pinned host buffer for small tables that kernels read (sweep point table): filled on the host,
+    // copied asynchronously; pinned_done = the last copy out of it (waited for before it is rewritten)
+    void* pinned = nullptr;
+    size_t pinned_bytes = 0;
+    hipEvent_t pinned_done = nullptr;
     // kCounterSlots x 8 partial counters; kernels add into slot (workgroup id mod kCounterSlots),
     // fold_counters() sums them into the caller's eight and leaves them zero again.
     unsigned long long* counter_slots = nullptr;
@@ -64,6 +69,9 @@ int ensure_device(sdr_ctx* ctx);
 // Device pointer to the reference-recurrence twiddle table for length n (n >= 2, power of two).
 int get_twiddles(sdr_ctx* ctx, size_t n, bool inverse, bool is_double, const void** d_table);
 int get_staging(sdr_ctx* ctx, int slot, size_t bytes, void** ptr);
+// Copies `bytes` of host data into staging slot `slot` on the context's stream without blocking it
+// (through the context's pinned buffer); *d_ptr = the device copy.
+int upload_table(sdr_ctx* ctx, const void* src, size_t bytes, int slot, void** d_ptr);
 constexpr int kCounterSlots = 1024;
 int get_counter_slots(sdr_ctx* ctx, unsigned long long** slots);
 // adds the slots and the counts that need no measuring (bits, symbols, OFDM symbols) into d_counters

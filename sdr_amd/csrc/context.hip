@@ -113,6 +113,23 @@ int get_staging(sdr_ctx* ctx, int slot, size_t bytes, void** ptr)
     return SDR_OK;
 }
 
+int upload_table(sdr_ctx* ctx, const void* src, size_t bytes, int slot, void** d_ptr)
+{
+    if (!ctx->pinned_done) SDR_HIP(hipEventCreateWithFlags(&ctx->pinned_done, hipEventDisableTiming));
+    else SDR_HIP(hipEventSynchronize(ctx->pinned_done));          // the previous table has left the pinned buffer
+    if (ctx->pinned_bytes < bytes) {
+        if (ctx->pinned) { SDR_HIP(hipHostFree(ctx->pinned)); ctx->pinned = nullptr; ctx->pinned_bytes = 0; }
+        const size_t want = bytes < 16384 ? 16384 : bytes;
+        SDR_HIP(hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault));
+        ctx->pinned_bytes = want;
+    }
+    memcpy(ctx->pinned, src, bytes);
+    SDR_TRY(get_staging(ctx, slot, bytes, d_ptr));
+    SDR_HIP(hipMemcpyAsync(*d_ptr, ctx->pinned, bytes, hipMemcpyHostToDevice, ctx->stream));
+    SDR_HIP(hipEventRecord(ctx->pinned_done, ctx->stream));
+    return SDR_OK;
+}
+
 int get_counter_slots(sdr_ctx* ctx, unsigned long long** slots)
 {
     if (!ctx->counter_slots) {
@@ -241,6 +258,8 @@ void sdr_destroy(sdr_ctx* ctx)
     for (auto& kv : ctx->twiddles) (void)hipFree(kv.second);
     for (auto& s : ctx->stage) if (s.ptr) (void)hipFree(s.ptr);
     if (ctx->counter_slots) (void)hipFree(ctx->counter_slots);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->pinned_done) (void)hipEventDestroy(ctx->pinned_done);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

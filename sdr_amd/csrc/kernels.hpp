@@ -38,6 +38,7 @@ int copy_shape_launch(sdr_ctx* ctx, const void* d_rx, uint32_t n_fft, uint32_t c
 // link.hip: frame generator, AWGN, Monte-Carlo link.
 int link_generate(sdr_ctx* ctx, const sdr_link_args& a);
 int link_ber(sdr_ctx* ctx, const sdr_link_args& a);
+int link_sweep(sdr_ctx* ctx, const sdr_sweep_args& a);
 bool tx_fused_ok(size_t n_fft, size_t cp, const void* d_in, const void* d_out);
 int tx_fused_launch(sdr_ctx* ctx, const void* d_in, uint32_t n_fft, uint32_t cp, uint64_t n_sym, void* d_out);
 

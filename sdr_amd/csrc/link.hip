@@ -11,14 +11,18 @@
 #include "rng.hpp"
 #include "link_fused.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <vector>
 
 namespace sdr {
 
 #define SDR_DECL_LINK(L) \
     int tx_fused_dispatch_##L(sdr_ctx*, const TxParams&, int); \
-    int mc_fused_dispatch_##L(sdr_ctx*, const McParams&, int);
+    int mc_fused_dispatch_##L(sdr_ctx*, const McParams&, int); \
+    int sweep_fused_dispatch_##L(sdr_ctx*, const SweepPointDev*, uint32_t, unsigned long long, const float2*, unsigned long long, unsigned long long*); \
+    int sweep_symbols_per_group_##L();
 SDR_DECL_LINK(6) SDR_DECL_LINK(7) SDR_DECL_LINK(8) SDR_DECL_LINK(9) SDR_DECL_LINK(10) SDR_DECL_LINK(11) SDR_DECL_LINK(12) SDR_DECL_LINK(13)
 #undef SDR_DECL_LINK
 
@@ -50,6 +54,35 @@ int mc_dispatch(sdr_ctx* ctx, unsigned log2n, const McParams& p, int mod)
         case 12: return mc_fused_dispatch_12(ctx, p, mod);
         case 13: return mc_fused_dispatch_13(ctx, p, mod);
         default: return fail(SDR_ERR_UNSUPPORTED, "n_fft = 2^%u has no fused kernel", log2n);
+    }
+}
+int sweep_dispatch(sdr_ctx* ctx, unsigned log2n, const SweepPointDev* d_pts, uint32_t n_points, unsigned long long blocks, const float2* tw, unsigned long long seed,
+                   unsigned long long* counters)
+{
+    switch (log2n) {
+        case 6: return sweep_fused_dispatch_6(ctx, d_pts, n_points, blocks, tw, seed, counters);
+        case 7: return sweep_fused_dispatch_7(ctx, d_pts, n_points, blocks, tw, seed, counters);
+        case 8: return sweep_fused_dispatch_8(ctx, d_pts, n_points, blocks, tw, seed, counters);
+        case 9: return sweep_fused_dispatch_9(ctx, d_pts, n_points, blocks, tw, seed, counters);
+        case 10: return sweep_fused_dispatch_10(ctx, d_pts, n_points, blocks, tw, seed, counters);
+        case 11: return sweep_fused_dispatch_11(ctx, d_pts, n_points, blocks, tw, seed, counters);
+        case 12: return sweep_fused_dispatch_12(ctx, d_pts, n_points, blocks, tw, seed, counters);
+        case 13: return sweep_fused_dispatch_13(ctx, d_pts, n_points, blocks, tw, seed, counters);
+        default: return fail(SDR_ERR_UNSUPPORTED, "n_fft = 2^%u has no fused kernel", log2n);
+    }
+}
+int sweep_symbols_per_group(unsigned log2n)
+{
+    switch (log2n) {
+        case 6: return sweep_symbols_per_group_6();
+        case 7: return sweep_symbols_per_group_7();
+        case 8: return sweep_symbols_per_group_8();
+        case 9: return sweep_symbols_per_group_9();
+        case 10: return sweep_symbols_per_group_10();
+        case 11: return sweep_symbols_per_group_11();
+        case 12: return sweep_symbols_per_group_12();
+        case 13: return sweep_symbols_per_group_13();
+        default: return 1;
     }
 }
 bool is_aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
@@ -253,6 +286,88 @@ int link_ber(sdr_ctx* ctx, const sdr_link_args& a)
         SDR_TRY(sdr_ofdm_demod_c32(ctx, &d));
     }
     return SDR_OK;
+}
+
+// The whole Eb/N0 sweep of one rank as ONE launch (model loop: app/QFDemoWindow.cpp:201-224, one
+// iteration per symbol; here every (modulation, noise level) point's symbol range at once).  The
+// host builds a table of the points, costliest modulation first so that the long workgroups are
+// dispatched first, and a grid in which workgroup b serves one run of symbol groups of one point;
+// counters land in row `index of the point in the caller's array` of d_counters.  Results are those
+// of one sdr_link_ber_c32 call per point (same random streams: they are keyed by the global
+// symbol index), without 70 launches of 50 microseconds each.
+int link_sweep(sdr_ctx* ctx, const sdr_sweep_args& a)
+{
+    if (a.struct_size != sizeof(sdr_sweep_args)) return fail(SDR_ERR_INVALID, "sdr_sweep_args.struct_size %u != %zu", a.struct_size, sizeof(sdr_sweep_args));
+    if (a.n_fft == 0 || !is_pow2(a.n_fft)) return fail(SDR_ERR_NOT_POW2, "%s", kPow2Message);
+    if (a.cp > a.n_fft) return fail(SDR_ERR_INVALID, "cyclic prefix %u longer than the FFT %u", a.cp, a.n_fft);
+    if (a.n_points == 0) return SDR_OK;
+    if (!a.points) return fail(SDR_ERR_INVALID, "null points");
+    if (!a.d_counters) return fail(SDR_ERR_INVALID, "null d_counters");
+    bool fused = !generic_only();
+    for (uint32_t i = 0; i < a.n_points; ++i) {
+        const sdr_sweep_point& pt = a.points[i];
+        if (!valid_mod(static_cast<int>(pt.mod))) return fail(SDR_ERR_INVALID, "point %u: unknown modulation %u", i, pt.mod);
+        if ((size_t(a.n_fft) * pt.mod) % 8 != 0) return fail(SDR_ERR_UNSUPPORTED, "point %u: n_fft*mod must be a multiple of 8 bits", i);
+        fused = fused && rx_fused_supported(a.n_fft, pt.mod);
+    }
+    if (!fused) {
+        // sizes without a fused kernel: one generic Monte-Carlo call per point
+        for (uint32_t i = 0; i < a.n_points; ++i) {
+            const sdr_sweep_point& pt = a.points[i];
+            sdr_link_args l = {};
+            l.struct_size = sizeof(sdr_link_args);
+            l.n_fft = a.n_fft; l.cp = a.cp; l.mod = pt.mod; l.seed = a.seed;
+            l.first_symbol = pt.first_symbol; l.n_sym = pt.n_sym; l.sigma = pt.sigma; l.llr_weight0 = pt.llr_weight0;
+            l.d_counters = a.d_counters + size_t(i) * 8;
+            SDR_TRY(link_ber(ctx, l));
+        }
+        return SDR_OK;
+    }
+    const unsigned log2n = ilog2(a.n_fft);
+    const unsigned long long spw = static_cast<unsigned long long>(sweep_symbols_per_group(log2n));
+    std::vector<uint32_t> order;
+    unsigned long long total_groups = 0;
+    for (uint32_t i = 0; i < a.n_points; ++i) {
+        if (a.points[i].n_sym == 0) continue;
+        order.push_back(i);
+        total_groups += (a.points[i].n_sym + spw - 1) / spw;
+    }
+    if (order.empty()) return SDR_OK;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return a.points[x].mod > a.points[y].mod; });
+    // sixteen workgroups per resident slot (eight slots per CU): the tail of the launch, where slots
+    // run empty, is then a few per cent of it, and the 6 atomics per wave at the end of a workgroup
+    // stay rare (measured alternatives: tools/sweepbench.py)
+    static const long knob = [] { const char* v = getenv("SDR_SWEEP_BLOCKS_PER_SLOT"); return v ? atol(v) : 0L; }();
+    const unsigned long long target = static_cast<unsigned long long>(ctx->num_cu) * 8ull * static_cast<unsigned long long>(knob > 0 ? knob : 16);
+    unsigned long long gpb = (total_groups + target - 1) / target;
+    if (gpb < 1) gpb = 1;
+    if (gpb > 0xFFFFFFFFull) gpb = 0xFFFFFFFFull;
+    std::vector<SweepPointDev> table(order.size());
+    unsigned long long blocks = 0;
+    for (size_t j = 0; j < order.size(); ++j) {
+        const sdr_sweep_point& pt = a.points[order[j]];
+        SweepPointDev& d = table[j];
+        d.first_symbol = pt.first_symbol;
+        d.n_sym = pt.n_sym;
+        d.n_groups = (pt.n_sym + spw - 1) / spw;
+        d.first_block = blocks;
+        d.sigma = pt.sigma;
+        d.w0 = pt.llr_weight0;
+        const float e = static_cast<float>(grid_energy(static_cast<int>(pt.mod)));
+        d.norm = 1.0f / std::sqrt(e);
+        d.inorm = std::sqrt(e);
+        d.mod = pt.mod;
+        d.row = order[j];
+        d.groups_per_block = static_cast<uint32_t>(gpb);
+        d.reserved = 0;
+        blocks += (d.n_groups + gpb - 1) / gpb;
+    }
+    const void* twf = nullptr;
+    SDR_TRY(get_twiddles(ctx, a.n_fft, false, false, &twf));
+    void* d_table = nullptr;
+    SDR_TRY(upload_table(ctx, table.data(), table.size() * sizeof(SweepPointDev), 8, &d_table));
+    return sweep_dispatch(ctx, log2n, static_cast<const SweepPointDev*>(d_table), static_cast<uint32_t>(table.size()), blocks, static_cast<const float2*>(twf), a.seed,
+                          reinterpret_cast<unsigned long long*>(a.d_counters));
 }
 
 } // namespace sdr

@@ -338,39 +338,43 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
 #define SDR_MC_ATTR
 #endif
 
+// One workgroup's share of one (modulation, noise level) point of a Monte-Carlo run.
+struct McWork {
+    unsigned long long* counters;      // the point's eight counters
+    unsigned long long n_sym;          // symbols of the point handled by this launch
+    unsigned long long seed;
+    unsigned long long first_symbol;   // global index of the point's first symbol in this launch
+    unsigned long long grp_begin, grp_end;   // symbol groups of the point this workgroup runs
+    float sigma, w0, norm, inorm;
+    bool count_ofdm;                   // this workgroup adds n_sym to counters[4]
+};
+
+template <int LOG2N>
+struct McLds {
+    using O = PlanOps<LOG2N>;
+    static constexpr int DATA_BYTES = O::max_sym_bytes() * O::kSPW;
+    static constexpr int TW_BYTES = O::kMidCount * 8;
+    static constexpr int TIME_BYTES = O::kN * 8 * O::kSPW;
+    static constexpr int BYTES = DATA_BYTES + TW_BYTES + TIME_BYTES + 16;
+};
+
+// generate -> IFFT -> + noise -> FFT -> demap -> count for the symbol groups [grp_begin, grp_end) of
+// one point.  The modulation is a template parameter; set-up that does not depend on it (addresses,
+// twiddles) is the caller's, so that one kernel can switch between several bodies.
 template <int LOG2N, int MI, int MQ>
-__global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) SDR_MC_ATTR mc_fused_kernel(const McParams p)
+__device__ __forceinline__ void mc_body(const McWork& p, unsigned char* lds, const FftAddr<LOG2N>& addr, const FftTwiddles<LOG2N>& tw_fwd)
 {
     using O = PlanOps<LOG2N>;
     using A = FftAddr<LOG2N>;
     constexpr int N = O::kN, E = O::kE, TPS = O::kTPS, SPW = O::kSPW;
     constexpr int BPS = MI + MQ;
-    constexpr int SYM_BYTES = O::max_sym_bytes();
-    constexpr int DATA_BYTES = SYM_BYTES * SPW;
-    constexpr int TW_BYTES = O::kMidCount * 8;
-    constexpr int TIME_BYTES = N * 8 * SPW;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[DATA_BYTES + TW_BYTES + TIME_BYTES + 16];
-    float2* lds_time = reinterpret_cast<float2*>(lds + DATA_BYTES + TW_BYTES);
-
+    float2* lds_time = reinterpret_cast<float2*>(lds + McLds<LOG2N>::DATA_BYTES + McLds<LOG2N>::TW_BYTES);
     const int tid = threadIdx.x;
     const int slot = tid / TPS;
     const int t = tid % TPS;
-    A addr;
-    addr.init(t, slot, SYM_BYTES);
-    // One twiddle set serves both directions: the inverse transform runs on the forward table
-    // with conjugated butterflies (rx_fused.hpp, bfly<CONJ>).  That can differ from the true
-    // inverse table only in the sign of exact zeros, which no counter can see; it halves the
-    // twiddle registers of this register-bound kernel.
-    FftTwiddles<LOG2N> tw_fwd;
-    tw_fwd.init(p.tw_fwd, reinterpret_cast<float2*>(lds + DATA_BYTES), tid, addr);
-    if constexpr (O::kMidCount > 0) __syncthreads();
 
     unsigned long long c_bit = 0, c_sym = 0, c_abs = 0, c_sign = 0, c_n = 0;
-    const unsigned long long n_groups = (p.n_sym + SPW - 1) / SPW;
-    const unsigned long long grp_begin = static_cast<unsigned long long>(blockIdx.x) * p.groups_per_wg;
-    const unsigned long long grp_end = (grp_begin + p.groups_per_wg < n_groups) ? grp_begin + p.groups_per_wg : n_groups;
-
-    for (unsigned long long grp = grp_begin; grp < grp_end; ++grp) {
+    for (unsigned long long grp = p.grp_begin; grp < p.grp_end; ++grp) {
         unsigned long long sym = grp * SPW + slot;
         const bool active = sym < p.n_sym;
         if (!active) sym = p.n_sym - 1;
@@ -462,7 +466,93 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) SDR_MC_ATTR mc_fused_kern
         atomicAdd(&p.counters[5], c_abs);
         atomicAdd(&p.counters[6], c_sign);
     }
-    if (blockIdx.x == 0 && tid == 0) atomicAdd(&p.counters[4], p.n_sym);
+    if (p.count_ofdm && tid == 0) atomicAdd(&p.counters[4], p.n_sym);
+}
+
+template <int LOG2N, int MI, int MQ>
+__global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) SDR_MC_ATTR mc_fused_kernel(const McParams p)
+{
+    using O = PlanOps<LOG2N>;
+    constexpr int SPW = O::kSPW;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[McLds<LOG2N>::BYTES];
+    const int tid = threadIdx.x;
+    FftAddr<LOG2N> addr;
+    addr.init(tid % O::kTPS, tid / O::kTPS, O::max_sym_bytes());
+    // One twiddle set serves both directions: the inverse transform runs on the forward table
+    // with conjugated butterflies (rx_fused.hpp, bfly<CONJ>).  That can differ from the true
+    // inverse table only in the sign of exact zeros, which no counter can see; it halves the
+    // twiddle registers of this register-bound kernel.
+    FftTwiddles<LOG2N> tw_fwd;
+    tw_fwd.init(p.tw_fwd, reinterpret_cast<float2*>(lds + McLds<LOG2N>::DATA_BYTES), tid, addr);
+    if constexpr (O::kMidCount > 0) __syncthreads();
+
+    const unsigned long long n_groups = (p.n_sym + SPW - 1) / SPW;
+    McWork w;
+    w.counters = p.counters;
+    w.n_sym = p.n_sym; w.seed = p.seed; w.first_symbol = p.first_symbol;
+    w.grp_begin = static_cast<unsigned long long>(blockIdx.x) * p.groups_per_wg;
+    w.grp_end = (w.grp_begin + p.groups_per_wg < n_groups) ? w.grp_begin + p.groups_per_wg : n_groups;
+    w.sigma = p.sigma; w.w0 = p.w0; w.norm = p.norm; w.inorm = p.inorm;
+    w.count_ofdm = blockIdx.x == 0;
+    mc_body<LOG2N, MI, MQ>(w, lds, addr, tw_fwd);
+}
+
+// ---- the whole Eb/N0 sweep in ONE launch --------------------------------------------------------
+// Device-side description of one sweep point (host: link.hip builds the table, sorted so that the
+// costliest modulations are dispatched first).  Workgroup b works on the point with the largest
+// first_block <= b, on symbol groups [(b - first_block) * groups_per_block, ...).
+struct SweepPointDev {
+    unsigned long long first_symbol;
+    unsigned long long n_sym;
+    unsigned long long n_groups;
+    unsigned long long first_block;
+    float sigma, w0, norm, inorm;
+    uint32_t mod;
+    uint32_t row;                  // row of the caller's counter array
+    uint32_t groups_per_block;
+    uint32_t reserved;
+};
+static_assert(sizeof(SweepPointDev) == 64, "one point per 64 bytes");
+
+template <int LOG2N>
+__global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) SDR_MC_ATTR sweep_fused_kernel(const SweepPointDev* __restrict__ pts, uint32_t n_points, const float2* __restrict__ tw,
+                                                                                      unsigned long long seed, unsigned long long* __restrict__ counters)
+{
+    using O = PlanOps<LOG2N>;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[McLds<LOG2N>::BYTES];
+    const int tid = threadIdx.x;
+    FftAddr<LOG2N> addr;
+    addr.init(tid % O::kTPS, tid / O::kTPS, O::max_sym_bytes());
+    FftTwiddles<LOG2N> tw_fwd;
+    tw_fwd.init(tw, reinterpret_cast<float2*>(lds + McLds<LOG2N>::DATA_BYTES), tid, addr);
+    if constexpr (O::kMidCount > 0) __syncthreads();
+
+    // uniform over the workgroup: the table is read through scalar loads
+    const unsigned long long b = blockIdx.x;
+    uint32_t lo = 0, hi = n_points;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (pts[mid].first_block <= b) lo = mid; else hi = mid;
+    }
+    const SweepPointDev pt = pts[lo];
+    const unsigned long long local = b - pt.first_block;
+    McWork w;
+    w.counters = counters + static_cast<size_t>(pt.row) * 8;
+    w.n_sym = pt.n_sym; w.seed = seed; w.first_symbol = pt.first_symbol;
+    w.grp_begin = local * pt.groups_per_block;
+    w.grp_end = (w.grp_begin + pt.groups_per_block < pt.n_groups) ? w.grp_begin + pt.groups_per_block : pt.n_groups;
+    w.sigma = pt.sigma; w.w0 = pt.w0; w.norm = pt.norm; w.inorm = pt.inorm;
+    w.count_ofdm = local == 0;
+    if (w.grp_begin >= w.grp_end) return;          // uniform; the host never makes such a block
+    switch (pt.mod) {
+        case 1: mc_body<LOG2N, 1, 0>(w, lds, addr, tw_fwd); break;
+        case 2: mc_body<LOG2N, 1, 1>(w, lds, addr, tw_fwd); break;
+        case 4: mc_body<LOG2N, 2, 2>(w, lds, addr, tw_fwd); break;
+        case 6: mc_body<LOG2N, 3, 3>(w, lds, addr, tw_fwd); break;
+        case 8: mc_body<LOG2N, 4, 4>(w, lds, addr, tw_fwd); break;
+        case 10: mc_body<LOG2N, 5, 5>(w, lds, addr, tw_fwd); break;
+        default: break;                            // the host validates modulations
+    }
 }
 
 inline unsigned long long resident_groups_per_wg(sdr_ctx* ctx, unsigned long long n_groups, int wg_per_cu)
@@ -489,6 +579,18 @@ int launch_tx_fused(sdr_ctx* ctx, const TxParams& p)
     hipLaunchKernelGGL((tx_fused_kernel<LOG2N, MI, MQ, SRC_GLOBAL, NOISE>), dim3(static_cast<unsigned>(blocks)), dim3(O::kWG), 0, ctx->stream, q);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(e, "tx_fused_kernel launch");
+    return SDR_OK;
+}
+
+template <int LOG2N>
+int launch_sweep_fused(sdr_ctx* ctx, const SweepPointDev* d_pts, uint32_t n_points, unsigned long long blocks, const float2* tw, unsigned long long seed, unsigned long long* counters)
+{
+    using O = PlanOps<LOG2N>;
+    if (blocks == 0) return SDR_OK;
+    if (blocks > 0x7FFFFFFFull) return fail(SDR_ERR_UNSUPPORTED, "sweep too large for one launch");
+    hipLaunchKernelGGL((sweep_fused_kernel<LOG2N>), dim3(static_cast<unsigned>(blocks)), dim3(O::kWG), 0, ctx->stream, d_pts, n_points, tw, seed, counters);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, "sweep_fused_kernel launch");
     return SDR_OK;
 }
 

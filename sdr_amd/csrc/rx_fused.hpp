@@ -389,6 +389,9 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 #ifndef SDR_EQ_WPE
 #define SDR_EQ_WPE 2
 #endif
+#ifndef SDR_EQ_NOLOOP
+#define SDR_EQ_NOLOOP 0
+#endif
 #ifndef SDR_ALIAS_FROM
 #define SDR_ALIAS_FROM 13
 #endif
@@ -443,7 +446,7 @@ struct RxShape {
     // beside LLRs: 63 -> 68 %; N = 8192: 56 -> 71 %).  Counting variants then end every symbol with
     // four atomics per wave on the 1024 counter slots, which measured no slower than runs of eight.
     // (The name is historical: the run of two is written out, see `process` in the kernel.)
-    static constexpr bool LOOP = EQ && !LATE_TAPS;
+    static constexpr bool LOOP = EQ && !LATE_TAPS && !SDR_EQ_NOLOOP;
 
     // Waves per SIMD.  Lower bound = register budget: the tap-holding and FULL variants must not
     // drift to 256+ registers (one wave per SIMD); at N = 8192 (E = 32) FULL variants are held to

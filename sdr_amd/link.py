@@ -87,6 +87,19 @@ def plan_sweep(mods: Sequence[int], ebn0_db: Dict[int, Sequence[float]], n_fft: 
     return pts
 
 
+def rank_points(points: Sequence[SweepPoint], n_fft: int, rank: int, world: int) -> List[Tuple[int, float, float, int, int]]:
+    """This rank's share of every point as the rows of an sdr_link_sweep_c32 point table:
+    (modulation bits, noise sigma, LLR weight, first global symbol, symbols).  Ranks take contiguous
+    frame ranges (shard_frames); a rank without frames of a point keeps the row with 0 symbols, so
+    counter rows line up across ranks for the all-reduce."""
+    rows = []
+    for p in points:
+        first, count = shard_frames(p.n_frames, rank, world)
+        rows.append((p.mod_bits, noise_sigma(n_fft, p.mod_bits, p.ebn0_db), llr_weight(p.mod_bits, p.ebn0_db),
+                     (p.first_frame + first) * SYMBOLS_PER_FRAME, count * SYMBOLS_PER_FRAME))
+    return rows
+
+
 def run_sweep(points: Sequence[SweepPoint], n_fft: int, cp: int, seed: int, rank: int, world: int,
               count_fn: Callable[[SweepPoint, int, int, float, float], Sequence[int]],
               all_reduce_fn: Callable[[List[int]], List[int]] = None) -> SweepResult:

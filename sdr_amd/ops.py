@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 from . import capi
-from .capi import DemodArgs, LinkArgs, check
+from .capi import DemodArgs, LinkArgs, SweepArgs, SweepPoint, check
 
 MODS = {"bpsk": 1, "qpsk": 2, "16qam": 4, "64qam": 6, "256qam": 8, "1024qam": 10}
 
@@ -266,4 +266,24 @@ class Context:
         a = self._link_args(n_fft, cp, mod, seed, first_symbol, n_sym, sigma, 0, llr_weight)
         a.d_counters = counters.data_ptr()
         check(self.lib.sdr_link_ber_c32(self._h, ctypes.byref(a)))
+        return counters
+
+    def link_sweep(self, n_fft: int, cp: int, seed: int, points, counters: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """sdr_link_sweep_c32: every (modulation, noise level) point of a sweep in ONE launch.
+        points = sequence of (mod, sigma, llr_weight0, first_symbol, n_sym); counters = int64
+        tensor (n_points, 8) on the device, accumulated into (created zeroed when None)."""
+        n = len(points)
+        if counters is None:
+            counters = torch.zeros((n, 8), dtype=torch.int64, device=self.torch_device)
+        _need(counters, torch.int64, "counters", n * 8)
+        table = (SweepPoint * max(n, 1))()
+        for i, (mod, sigma, w0, first, count) in enumerate(points):
+            table[i].mod, table[i].sigma, table[i].llr_weight0 = mod_bits(mod), float(sigma), float(w0)
+            table[i].first_symbol, table[i].n_sym = int(first), int(count)
+        a = SweepArgs()
+        a.struct_size = ctypes.sizeof(SweepArgs)
+        a.n_fft, a.cp, a.n_points, a.seed = n_fft, cp, n, seed
+        a.points = ctypes.cast(table, ctypes.POINTER(SweepPoint))
+        a.d_counters = counters.data_ptr()
+        check(self.lib.sdr_link_sweep_c32(self._h, ctypes.byref(a)))
         return counters

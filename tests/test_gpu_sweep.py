@@ -1,0 +1,104 @@
+"""The whole Eb/N0 sweep as one launch (sdr_link_sweep_c32) and the sweep under several ranks:
+counters bit-equal to one Monte-Carlo call per point, to the oracle, and independent of how the
+frames are split over processes."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("n,cp", [(64, 16), (256, 64), (1024, 256), (2048, 512), (32, 8)])
+def test_sweep_one_launch_equals_per_point_calls(ctx, oracle, n, cp):
+    from sdr_amd.link import noise_sigma, llr_weight
+    rng = np.random.default_rng(n)
+    mods = [2, 4, 6, 8, 1, 10, 4, 2]
+    points, g0 = [], 7
+    for i, m in enumerate(mods):
+        db = {1: 3.0, 2: 4.0, 4: 8.0, 6: 13.0, 8: 18.0, 10: 23.0}[m] + float(rng.integers(0, 3))
+        n_sym = 0 if i == 3 else int(rng.integers(1, 40 if n >= 1024 else 200))      # one empty point, ragged sizes
+        points.append((m, noise_sigma(n, m, db), llr_weight(m, db), g0, n_sym))
+        g0 += n_sym + int(rng.integers(0, 5))
+    got = ctx.link_sweep(n, cp, 31, points)
+    again = ctx.link_sweep(n, cp, 31, points, got.clone())                             # accumulates
+    torch.cuda.synchronize()
+    got = got.cpu().numpy()
+    assert np.array_equal(again.cpu().numpy(), 2 * got)
+    for i, (m, sigma, w, first, n_sym) in enumerate(points):
+        if n_sym == 0:
+            assert not got[i].any()
+            continue
+        one = ctx.link_ber(n, cp, m, 31, first, n_sym, sigma, w).cpu().numpy()
+        assert np.array_equal(got[i], one), (i, m)
+        want = oracle.link_ber(n, cp, m, 31, first, n_sym, np.float32(sigma), np.float32(w))
+        assert np.array_equal(got[i].astype(np.uint64), want), (i, m)
+        assert got[i][1] == n_sym * n * m and got[i][4] == n_sym and got[i][0] > 0
+
+
+def test_sweep_argument_errors(ctx):
+    from sdr_amd.capi import SdrError, SDR_ERR_INVALID, SDR_ERR_NOT_POW2
+    with pytest.raises(SdrError) as e:
+        ctx.link_sweep(1024, 256, 1, [(3, 0.1, 1.0, 0, 14)])
+    assert e.value.code == SDR_ERR_INVALID
+    with pytest.raises(SdrError) as e:
+        ctx.link_sweep(1000, 256, 1, [(4, 0.1, 1.0, 0, 14)])
+    assert e.value.code == SDR_ERR_NOT_POW2
+    assert not ctx.link_sweep(1024, 256, 1, []).numel()
+    assert not ctx.link_sweep(1024, 256, 1, [(4, 0.1, 1.0, 0, 0)]).any()
+
+
+def test_large_sweep_is_split_invariant(ctx):
+    """1e8 bits over 12 points: one launch for everything equals the sum of three launches that
+    split every point's symbols 3 ways (what three ranks would run)."""
+    from sdr_amd import link
+    pts = link.plan_sweep([2, 4, 6, 8], {2: [2, 6], 4: [4, 8, 10], 6: [8, 12, 14], 8: [14, 18, 20, 22]}, 1024, 1e8)
+    whole = ctx.link_sweep(1024, 256, 5, link.rank_points(pts, 1024, 0, 1)).cpu().numpy()
+    parts = sum(ctx.link_sweep(1024, 256, 5, link.rank_points(pts, 1024, r, 3)).cpu().numpy() for r in range(3))
+    assert np.array_equal(whole, parts)
+    for p, row in zip(pts, whole):
+        assert row[1] == p.n_frames * link.SYMBOLS_PER_FRAME * 1024 * p.mod_bits
+        ber, th = row[0] / row[1], link.theory_ber(p.mod_bits, p.ebn0_db)
+        assert 0.6 * th < ber < 1.6 * th, (p, ber, th)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _run_sweep(ranks, extra):
+    env = dict(os.environ)
+    env["SDR_BENCH_BACKEND"] = "gloo"            # ranks share device 0; the counter all-reduce goes over gloo
+    base = [os.path.join(ROOT, "ber_sweep.py"), "--bits", "6e7", "--n-fft", "512", "--cp", "128", "--mods", "2", "4", "6", "--step-db", "5"] + extra
+    if ranks == 1:
+        cmd = [sys.executable] + base
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port())] + base
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    return json.loads(line)
+
+
+def test_sweep_under_several_ranks_on_one_gpu():
+    """The GPU path under N ranks without N GPUs: 3 fresh processes share device 0, each runs its
+    frame share of every point in one launch, one all-reduce (gloo here, RCCL on a real node) sums
+    the counters.  Identical to the single-process sweep, and to the per-point form."""
+    one = _run_sweep(1, [])
+    three = _run_sweep(3, [])
+    assert three["n_gpus"] == 3 and three["launches_per_sweep"] == 1
+    assert three["counters"] == one["counters"]
+    assert one["checksum_bit_errors"] > 0 and one["total_bits"] >= 6e7
+    per_point = _run_sweep(1, ["--per-point"])
+    assert per_point["counters"] == one["counters"]

@@ -98,3 +98,19 @@ def test_sweep_gloo_world2_matches_single_rank():
     pts = plan_sweep([2, 6], {2: [3.0], 6: [10.0, 12.0]}, n_fft, 2e5)
     ref = run_sweep(pts, n_fft, cp, seed, 0, 1, _oracle_count(n_fft, cp, seed))
     assert got[0] == ref.counters and got[1] == ref.counters
+
+
+def test_rank_points_rows_line_up_and_tile():
+    from sdr_amd.link import plan_sweep, rank_points, SYMBOLS_PER_FRAME, noise_sigma
+    pts = plan_sweep([2, 4, 8], {2: [0, 1], 4: [3.0], 8: [20.0, 21.0]}, 256, 4e6)
+    for world in (1, 2, 3, 8, 64):
+        rows = [rank_points(pts, 256, r, world) for r in range(world)]
+        for i, p in enumerate(pts):
+            pos = p.first_frame * SYMBOLS_PER_FRAME
+            for r in range(world):
+                mod, sigma, w, g0, n_sym = rows[r][i]
+                assert mod == p.mod_bits and sigma == noise_sigma(256, p.mod_bits, p.ebn0_db)
+                assert g0 == pos and n_sym % SYMBOLS_PER_FRAME == 0
+                pos += n_sym
+            assert pos == (p.first_frame + p.n_frames) * SYMBOLS_PER_FRAME
+
