@@ -15,6 +15,12 @@ extern "C" {
  * with the same access pattern and workgroup order, and no arithmetic. */
 int sdr_diag_copy_shape_c32(sdr_ctx* ctx, const void* d_rx, uint32_t n_fft, uint32_t cp, uint32_t mod, uint64_t n_sym, float* d_llr);
 
+/* Sets a run-time tuning knob of the receive kernels for every later launch of the process (the
+ * environment variables SDR_LDS_PAD / SDR_XCD_WINDOW / SDR_DEBUG give the initial values):
+ * "lds_pad" = unused dynamic LDS per workgroup in bytes (throttles resident workgroups per CU),
+ * "xcd_window" = window of the XCD-aware workgroup order (0 = natural order), "debug" = 0/1. */
+int sdr_diag_set_tuning(const char* name, long value);
+
 #ifdef __cplusplus
 }
 #endif

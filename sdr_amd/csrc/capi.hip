@@ -228,6 +228,8 @@ int sdr_diag_copy_shape_c32(sdr_ctx* ctx, const void* d_rx, uint32_t n_fft, uint
     return copy_shape_launch(ctx, d_rx, n_fft, cp, mod, n_sym, d_llr);
 }
 
+int sdr_diag_set_tuning(const char* name, long value) { return rx_set_tuning(name, value); }
+
 int sdr_zf_taps_c32(sdr_ctx* ctx, int mod, const void* d_chan, size_t n, float inv_n0, void* d_taps, float* d_weight)
 {
     SDR_TRY(ensure_device(ctx));

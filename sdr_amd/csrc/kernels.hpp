@@ -33,6 +33,8 @@ int rx_fused_launch(sdr_ctx* ctx, const sdr_demod_args& a, const RxWorkspace* ws
 // noalloc.hip: resolves the static scratch array of `device` (once per device) -- called by sdr_create
 int noalloc_setup_device(int device);
 int rx_fft_only_launch(sdr_ctx* ctx, const void* d_in, uint32_t n_fft, uint32_t cp, uint64_t n_sym, void* d_out);
+// measurement aid (sdr_amd_diag.h): changes a run-time tuning knob of the receive kernels
+int rx_set_tuning(const char* name, long value);
 int copy_shape_launch(sdr_ctx* ctx, const void* d_rx, uint32_t n_fft, uint32_t cp, uint32_t bps, uint64_t n_sym, float* d_out);
 
 // link.hip: frame generator, AWGN, Monte-Carlo link.

@@ -6,6 +6,7 @@
 #include "rx_fused.hpp"
 
 #include <cmath>
+#include <string>
 
 namespace sdr {
 
@@ -17,6 +18,24 @@ int rx_fused_dispatch_10(sdr_ctx*, const RxParams&, int, int);
 int rx_fused_dispatch_11(sdr_ctx*, const RxParams&, int, int);
 int rx_fused_dispatch_12(sdr_ctx*, const RxParams&, int, int);
 int rx_fused_dispatch_13(sdr_ctx*, const RxParams&, int, int);
+
+RxTuning& rx_tuning_mutable()
+{
+    static RxTuning t;            // C++11: initialised once (from the environment), thread-safe
+    return t;
+}
+
+int rx_set_tuning(const char* name, long value)
+{
+    if (!name) return fail(SDR_ERR_INVALID, "null knob name");
+    RxTuning& t = rx_tuning_mutable();
+    const std::string n(name);
+    if (n == "lds_pad") t.lds_pad = value;
+    else if (n == "xcd_window") t.xcd_window = value & ~7L;
+    else if (n == "debug") t.debug = value != 0;
+    else return fail(SDR_ERR_INVALID, "unknown tuning knob '%s'", name);
+    return SDR_OK;
+}
 
 namespace {
 

@@ -433,7 +433,33 @@ struct RxShape {
     static constexpr bool STG_ALIAS = STAGE && STG_BYTES <= DATA_BYTES && (O::kWG == 64 || LOG2N >= SDR_ALIAS_FROM || FULL);
 #endif
     static constexpr int STG_OFF = STG_ALIAS ? 0 : (DATA_BYTES + TW_BYTES + IDX_BYTES + REF_BYTES + 15) & ~15;
-    static constexpr int LDS_BYTES = (STG_ALIAS ? DATA_BYTES + TW_BYTES + IDX_BYTES + REF_BYTES : STG_OFF + STG_BYTES) + 16;
+    static constexpr int LDS_USED = (STG_ALIAS ? DATA_BYTES + TW_BYTES + IDX_BYTES + REF_BYTES : STG_OFF + STG_BYTES) + 16;
+    // Resident workgroups per CU of the LLR-only kernels at N <= 1024.  These kernels are bound by the
+    // memory system, and the memory system runs a 1 : bps/2 read/write mix FASTER with fewer symbols
+    // in flight (a copy of this shape: 5.4 TB/s at 16 waves per CU, 6.0 at 4-5, tools/membench6/7),
+    // while the kernel needs enough waves to cover its own latency: the optimum sits at 6-12
+    // workgroups per CU instead of the 16-32 that LDS and registers would allow.  Measured on one set
+    // of buffers per case (tools/occbench.py, profiles/r2_occupancy_single_allocation.txt): +2 to +5
+    // points.  The throttle is unused LDS; 0 = no throttle (N >= 2048, QPSK at 1024 and the variants
+    // with hard bits or counters measured best at what they already get).
+    static constexpr int wg_per_cu_target()
+    {
+#ifdef SDR_NO_WG_TARGET
+        return 0;
+#else
+        if (FULL || EQ || HARDONLY || !DEMAP) return 0;
+        switch (LOG2N) {
+            case 6: return BPS <= 8 ? (BPS == 4 ? 9 : 8) : 0;
+            case 7: return BPS <= 4 ? 6 : BPS == 6 ? 7 : BPS == 8 ? 8 : 0;
+            case 8: return BPS <= 4 ? 6 : BPS == 6 ? 8 : BPS == 8 ? 10 : 0;
+            case 9: return BPS == 2 ? 14 : BPS <= 8 ? 12 : 0;
+            case 10: return BPS == 4 ? 10 : BPS == 6 ? 9 : BPS == 8 ? 12 : 0;
+            default: return 0;
+        }
+#endif
+    }
+    static constexpr int LDS_THROTTLE = wg_per_cu_target() > 0 ? ((160 * 1024 / wg_per_cu_target()) & ~511) : 0;
+    static constexpr int LDS_BYTES = LDS_USED > LDS_THROTTLE ? LDS_USED : LDS_THROTTLE;
 
     // Alternative to holding the taps across a run of two symbols, OFF by default (measured within
     // a point of it at N = 2048 / 4096, worse at N = 1024): requested per symbol ahead of an exchange
@@ -592,14 +618,24 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
             const float2* eq_src = p.eq ? p.eq + tap_set * N : dummy;
             const float* wgt_src = p.wgt ? p.wgt + tap_set * N : reinterpret_cast<const float*>(dummy);
 #endif
+#ifdef SDR_EQ_NOLOAD    // experiment: no tap traffic at all, run-time values the compiler cannot fold
+            static_for<E>([&](auto M) { constexpr int m = M; eqv[m] = make_float2(p.w0, p.inorm); wv[m] = p.w0; });
+            (void)eq_src; (void)wgt_src;
+            if (true) return;
+#endif
             static_for<E / GO_>([&](auto Hh) {
                 constexpr int h = Hh;
                 const int k = O::reg_pos(LAST, h * GO_) | pos_last;
                 if constexpr (GO_ == 2) {
+#ifdef SDR_EQ_NT_TAPS
+                    const sdr_v4f v = __builtin_nontemporal_load(reinterpret_cast<const sdr_v4f*>(eq_src + k));
+                    const sdr_v2f u = __builtin_nontemporal_load(reinterpret_cast<const sdr_v2f*>(wgt_src + k));
+#else
                     const float4 v = *reinterpret_cast<const float4*>(eq_src + k);
+                    const float2 u = *reinterpret_cast<const float2*>(wgt_src + k);
+#endif
                     eqv[h * 2] = make_float2(v.x, v.y);
                     eqv[h * 2 + 1] = make_float2(v.z, v.w);
-                    const float2 u = *reinterpret_cast<const float2*>(wgt_src + k);
                     wv[h * 2] = u.x;
                     wv[h * 2 + 1] = u.y;
                 } else {
@@ -608,12 +644,14 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
             });
             }
         };
+#ifndef SDR_EQ_TAPS_AFTER
         if constexpr (PREFETCH_TAPS && !LATE_TAPS) {
             if (tap_set != held_set) {
                 held_set = tap_set;
                 load_taps();
             }
         }
+#endif
 
         // Reference bits of the symbol (counting only): requested ahead of the samples, parked
         // in LDS before the transform.  Unconditional (see the taps above); a
@@ -634,6 +672,14 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
 
         // ---- pass 0 ----
         load_symbol(grp, x);
+#ifdef SDR_EQ_TAPS_AFTER     // experiment: taps requested behind the samples
+        if constexpr (PREFETCH_TAPS && !LATE_TAPS) {
+            if (tap_set != held_set) {
+                held_set = tap_set;
+                load_taps();
+            }
+        }
+#endif
         if constexpr (FULL && DEMAP) {
             static_for<REF_PER_THREAD>([&](auto R) {
                 constexpr int r = R;
@@ -847,11 +893,8 @@ struct RxTuning {
         debug = getenv("SDR_DEBUG") != nullptr;
     }
 };
-inline const RxTuning& rx_tuning()
-{
-    static const RxTuning t;      // C++11: initialised once, thread-safe
-    return t;
-}
+RxTuning& rx_tuning_mutable();      // rx_fused.hip
+inline const RxTuning& rx_tuning() { return rx_tuning_mutable(); }
 
 template <int LOG2N, int MI, int MQ, bool FULL, bool EQ, bool HARDONLY = false>
 int launch_rx_fused(sdr_ctx* ctx, const RxParams& p)
