@@ -166,12 +166,55 @@ def time_workload(ctx, torch, dist, name, steps, warmup, world, rank, n_sym_over
     return res
 
 
+CHAIN = {
+    # BASELINE.json configs[2] at its stated size: FFT-2048, cp 512, 64-QAM, one channel realisation per
+    # 14-symbol frame, 18 dB, 4 Mi symbols (86 GB of samples, 206 GB of LLRs) in resident chunks
+    "fft2048_64qam_eq_4M_chain": dict(n_fft=2048, cp=512, bps=6, n_sym=1 << 22, chunk=(1 << 18) // 14 * 14, per=14, ebn0=18.0, seed=3),
+}
+
+
+def time_chain(ctx, torch, name, steps, warmup, n_sym_override=None):
+    """One step = the whole faded link over n_sym symbols: channel -> zero-forcing taps -> generator +
+    AWGN -> equalised demodulation to LLRs -> counters, chunk by chunk in one reused workspace, the
+    generator of chunk i+1 on a second stream beside the demodulation of chunk i (sdr_link_chain_c32)."""
+    from sdr_amd.link import noise_sigma
+    c = dict(CHAIN[name])
+    if n_sym_override:
+        c["n_sym"] = n_sym_override
+    sigma = noise_sigma(c["n_fft"], c["bps"], c["ebn0"])
+    inv_n0 = c["bps"] * 10 ** (c["ebn0"] / 10)
+    need = ctx.link_chain_workspace(c["n_fft"], c["cp"], c["bps"], c["n_sym"], c["chunk"], c["per"])
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(8, dtype=torch.int64, device="cuda")
+
+    def step():
+        ctx.link_chain(c["n_fft"], c["cp"], c["bps"], c["seed"], 0, c["n_sym"], c["chunk"], c["per"], sigma, inv_n0, workspace=ws, counters=cnt)
+
+    for _ in range(warmup):
+        step()
+    cnt.zero_()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    k = cnt.cpu().tolist()
+    b_sym = algorithmic_bytes_per_symbol(c["n_fft"], c["bps"])
+    return {"symbols": c["n_sym"], "chunk_symbols": c["chunk"], "chunks": -(-c["n_sym"] // c["chunk"]), "workspace_GB": need / 1e9,
+            "seconds_per_pass": dt, "sym_per_s": c["n_sym"] / dt, "llr_gbit_per_s": c["n_sym"] / dt * c["n_fft"] * c["bps"] / 1e9,
+            "demod_bytes_GBs": b_sym * c["n_sym"] / dt / 1e9, "generated_GBs": 8 * (c["n_fft"] + c["cp"]) * c["n_sym"] / dt / 1e9,
+            "bit_errors_per_pass": k[0] // steps, "bits_per_pass": k[1] // steps, "ber": (k[0] / k[1]) if k[1] else None,
+            "what": "generate (channel + AWGN) and demodulate (taps + weights, LLRs written, hard bits counted) overlapped on two streams, per pass over all symbols"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="fft1024_16qam_1M", choices=sorted(WORKLOADS))
+    ap.add_argument("--chain", default="", choices=[""] + sorted(CHAIN), help="only run this chunked whole-link configuration and print its JSON")
     ap.add_argument("--symbols", type=int, default=0, help="override symbols per GPU (debug)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra 64-QAM headline measurement")
@@ -203,6 +246,13 @@ def main():
 
     from sdr_amd.ops import Context
     ctx = Context(local_rank)
+    if args.chain:
+        r = time_chain(ctx, torch, args.chain, max(1, args.steps), max(1, min(args.warmup, 2)), args.symbols or None)
+        if rank == 0:
+            print(json.dumps({"metric": "whole faded link, OFDM symbols/s (generate + equalised demodulation to LLRs + counting, resident chunks)", "value": r["sym_per_s"],
+                              "unit": "OFDM symbols/s", "n_gpus": 1, "config": {"workload": args.chain}, **r}))
+        ctx.close()
+        return
     main_res = time_workload(ctx, torch, dist, args.workload, args.steps, args.warmup, world, rank, args.symbols or None)
     extra = {}
     if world == 1 and not args.no_extra and args.workload == "fft1024_16qam_1M" and not args.symbols:
@@ -219,6 +269,7 @@ def main():
             if r["with_eq"]:
                 extra[name]["hbm_frac_incl_tap_bytes"] = r["frac_incl_taps"]
                 extra[name]["tap_bytes_per_symbol"] = r["tap_bytes_per_symbol"]
+        extra["fft2048_64qam_eq_4M_chain"] = time_chain(ctx, torch, "fft2048_64qam_eq_4M_chain", 2, 1)      # configs[2] at its stated size
     if main_res.get("copy_shape_gbs"):
         extra["copy_of_same_shape"] = {"achieved_GBs": main_res["copy_shape_gbs"], "kernel_over_copy": main_res["roofline"]["achieved"] / main_res["copy_shape_gbs"],
                                        "what": "sdr_diag_copy_shape_c32: the kernel's bytes and access pattern with no arithmetic, same buffers"}

@@ -234,6 +234,43 @@ typedef struct sdr_sweep_args {
 } sdr_sweep_args;
 int sdr_link_sweep_c32(sdr_ctx* ctx, const sdr_sweep_args* args);
 
+/* Channel realisations for the faded link: H[set][k], unit-variance complex Gaussian from Philox
+ * block (k, set, stream tag); sets first_set .. first_set+n_sets-1, n_sets*n_fft c32 written. */
+int sdr_link_channel_c32(sdr_ctx* ctx, uint32_t n_fft, uint64_t seed, uint64_t first_set, size_t n_sets, void* d_chan);
+
+/* The whole faded link over MORE symbols than fit in memory (BASELINE.json configs[2]: FFT-2048,
+ * 64-QAM, per-subcarrier equalisation, 4 Mi symbols = 86 GB of samples and 206 GB of LLRs): symbols
+ * first_symbol .. first_symbol+n_sym-1 in resident chunks of chunk_symbols that REUSE one
+ * workspace.  Per chunk: channel realisation per set of sym_per_set symbols -> zero-forcing taps and
+ * LLR weights (sdr_zf_taps_c32, perfect channel knowledge) -> frame generator through that channel
+ * + AWGN -> sdr_ofdm_demod_c32 with taps and weights (LLRs of the chunk into the workspace unless
+ * no_llr, hard bits compared with the transmitted ones) -> d_counters (8 uint64, accumulated into).
+ * The generator of chunk i+1 runs on a second stream beside the demodulation of chunk i (two sample
+ * buffers).  Results do not depend on chunk_symbols.  first_symbol and chunk_symbols must be
+ * multiples of sym_per_set (>= 1); n_fft 64..8192, even cp.  The workspace (device memory,
+ * 256-byte aligned, sdr_link_chain_workspace bytes) is the caller's; d_llr_chunk (optional) receives
+ * where the LLRs of the LAST chunk lie in it.  Model loop: app/QFDemoWindow.cpp:201-224. */
+typedef struct sdr_chain_args {
+    uint32_t struct_size;       /* = sizeof(sdr_chain_args) */
+    uint32_t n_fft;
+    uint32_t cp;
+    uint32_t mod;               /* sdr_modulation */
+    uint64_t seed;
+    uint64_t first_symbol;
+    uint64_t n_sym;
+    uint64_t chunk_symbols;
+    uint32_t sym_per_set;
+    uint32_t no_llr;            /* 1: counters only, no LLR chunk in the workspace */
+    float sigma;                /* per-component noise standard deviation, time domain */
+    float inv_n0;               /* 1/N0 for the LLR weights */
+    void* d_workspace;
+    uint64_t workspace_bytes;
+    uint64_t* d_counters;
+    float** d_llr_chunk;        /* optional out (host pointer to a device pointer) */
+} sdr_chain_args;
+int sdr_link_chain_workspace(const sdr_chain_args* args, uint64_t* bytes);
+int sdr_link_chain_c32(sdr_ctx* ctx, const sdr_chain_args* args);
+
 /* ---- Streaming ingest ------------------------------------------------
  * What sits in front of the path in the reference is a host-side ring that is fed one OFDM
  * symbol at a time (utils::sliding_buffer, lib/inc/sliding_buffer.hpp:14-104, filled at

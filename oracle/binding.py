@@ -196,6 +196,23 @@ def link_ber(n_fft, cp, bps, seed, g0, n_sym, sigma, w0=1.0, counters=None):
     return counters
 
 
+def link_channel(n_fft, seed, first_set, n_sets):
+    chan = np.zeros((n_sets, n_fft), dtype=np.complex64)
+    rc = lib().orc_link_channel_c32(c_uint32(n_fft), c_uint64(seed), c_uint64(first_set), c_size_t(n_sets), _p(chan))
+    assert rc == 0, rc
+    return chan
+
+
+def link_chain(n_fft, cp, bps, seed, g0, n_sym, sym_per_set, sigma, inv_n0, counters=None, want_llr=False):
+    if counters is None:
+        counters = np.zeros(8, dtype=np.uint64)
+    llr = np.zeros((n_sym, n_fft, bps), dtype=np.float32) if want_llr else None
+    rc = lib().orc_link_chain_c32(c_uint32(n_fft), c_uint32(cp), c_int(bps), c_uint64(seed), c_uint64(g0), c_size_t(n_sym), c_uint32(sym_per_set),
+                                  c_float(sigma), c_float(inv_n0), _p(counters), _p(llr))
+    assert rc == 0, rc
+    return (counters, llr) if want_llr else counters
+
+
 def count_bit_errors(a, b):
     a = _c(a, np.uint8).ravel()
     b = _c(b, np.uint8).ravel()

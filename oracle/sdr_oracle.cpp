@@ -336,6 +336,7 @@ inline void philox4x32_10(const std::uint32_t ctr[4], const std::uint32_t key[2]
 constexpr std::uint32_t kStreamTx = 0x54580000u;      // transmitted indices
 constexpr std::uint32_t kStreamNoise = 0x4E5A0000u;   // payload noise
 constexpr std::uint32_t kStreamCp = 0x43500000u;      // noise on cyclic-prefix samples
+constexpr std::uint32_t kStreamChan = 0x43480000u;    // channel realisations (one per set of symbols)
 
 // Transmitted constellation index of subcarrier k of global OFDM symbol g:
 // one Philox block serves the 8 subcarriers {r, r+stride, ...}, stride = max(N/8,1);
@@ -771,6 +772,62 @@ int orc_link_ber_c32(std::uint32_t n_fft, std::uint32_t cp, int bps, std::uint64
         const std::uint64_t g = g0 + s;
         generate_symbol(c, n_fft, cp, seed, g, sigma, nullptr, samples.data(), tx.data());
         demod_symbol(c, n_fft, cp, samples.data(), nullptr, nullptr, w0, nullptr, llr.data(), rx.data());
+        for (std::uint32_t k = 0; k < n_fft; ++k) {
+            const std::uint32_t diff = tx[k] ^ rx[k];
+            counters[0] += popcount32(diff);
+            counters[2] += (diff != 0);
+            llr_stats(llr.data() + static_cast<std::size_t>(k) * bps, bps, tx[k], counters[5], counters[6]);
+        }
+        counters[1] += static_cast<std::uint64_t>(n_fft) * bps;
+        counters[3] += n_fft;
+        counters[4] += 1;
+    }
+    return 0;
+}
+
+// Channel realisations (X4, BASELINE.json configs[2]: "random unit-variance complex Gaussian H_k, one
+// set per 14-symbol frame"): H[set][k] = Box-Muller pair of Philox block (k, set, stream tag) with
+// standard deviation sqrt(1/2) per component.  Sets first_set .. first_set + n_sets - 1.
+int orc_link_channel_c32(std::uint32_t n_fft, std::uint64_t seed, std::uint64_t first_set, std::size_t n_sets, float* chan_out)
+{
+    const std::uint32_t key[2] = { static_cast<std::uint32_t>(seed), static_cast<std::uint32_t>(seed >> 32) };
+    for (std::size_t s = 0; s < n_sets; ++s) {
+        const std::uint64_t set = first_set + s;
+        for (std::uint32_t k = 0; k < n_fft; ++k) {
+            const std::uint32_t ctr[4] = { k, static_cast<std::uint32_t>(set), static_cast<std::uint32_t>(set >> 32), kStreamChan };
+            std::uint32_t r[4];
+            philox4x32_10(ctr, key, r);
+            gaussian_pair(r[0], r[1], 0.70710678f, chan_out[2 * (s * n_fft + k)], chan_out[2 * (s * n_fft + k) + 1]);
+        }
+    }
+    return 0;
+}
+
+// The whole faded link (configs[2]): per set of sym_per_set symbols a channel realisation, zero-forcing
+// taps and LLR weights from it (perfect channel knowledge), generate -> demodulate with them -> count.
+// g0 must be a multiple of sym_per_set.  llr_out (optional): n_sym*N*bps LLRs.
+int orc_link_chain_c32(std::uint32_t n_fft, std::uint32_t cp, int bps, std::uint64_t seed, std::uint64_t g0, std::size_t n_sym, std::uint32_t sym_per_set,
+                       float sigma, float inv_n0, std::uint64_t* counters /* 8, accumulated into */, float* llr_out)
+{
+    Constellation c;
+    if (!make_constellation(bps, c)) return 1;
+    if (n_fft == 0 || (n_fft & (n_fft - 1)) != 0 || sym_per_set == 0 || g0 % sym_per_set != 0) return 1;
+    std::vector<unsigned> tx(n_fft), rx(n_fft);
+    std::vector<float> samples(2 * (static_cast<std::size_t>(n_fft) + cp));
+    std::vector<float> llr(static_cast<std::size_t>(n_fft) * bps);
+    std::vector<float> chan(2 * static_cast<std::size_t>(n_fft)), taps(2 * static_cast<std::size_t>(n_fft)), wgt(n_fft);
+    std::uint64_t have_set = ~std::uint64_t(0);
+    for (std::size_t s = 0; s < n_sym; ++s) {
+        const std::uint64_t g = g0 + s;
+        const std::uint64_t set = g / sym_per_set;
+        if (set != have_set) {
+            orc_link_channel_c32(n_fft, seed, set, 1, chan.data());
+            orc_zf_taps_f32(bps, chan.data(), n_fft, inv_n0, taps.data(), wgt.data());
+            have_set = set;
+        }
+        generate_symbol(c, n_fft, cp, seed, g, sigma, chan.data(), samples.data(), tx.data());
+        demod_symbol(c, n_fft, cp, samples.data(), taps.data(), wgt.data(), 0.0f, nullptr, llr.data(), rx.data());
+        if (llr_out) std::memcpy(llr_out + s * llr.size(), llr.data(), llr.size() * sizeof(float));
         for (std::uint32_t k = 0; k < n_fft; ++k) {
             const std::uint32_t diff = tx[k] ^ rx[k];
             counters[0] += popcount32(diff);

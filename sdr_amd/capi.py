@@ -92,6 +92,27 @@ class SweepArgs(Structure):
     ]
 
 
+class ChainArgs(Structure):
+    _fields_ = [
+        ("struct_size", c_uint32),
+        ("n_fft", c_uint32),
+        ("cp", c_uint32),
+        ("mod", c_uint32),
+        ("seed", c_uint64),
+        ("first_symbol", c_uint64),
+        ("n_sym", c_uint64),
+        ("chunk_symbols", c_uint64),
+        ("sym_per_set", c_uint32),
+        ("no_llr", c_uint32),
+        ("sigma", c_float),
+        ("inv_n0", c_float),
+        ("d_workspace", c_void_p),
+        ("workspace_bytes", c_uint64),
+        ("d_counters", c_void_p),
+        ("d_llr_chunk", POINTER(c_void_p)),
+    ]
+
+
 class PipeConfig(Structure):
     _fields_ = [
         ("struct_size", c_uint32),
@@ -169,6 +190,9 @@ SIGNATURES = {
     "sdr_link_generate_c32": (c_int, [c_void_p, POINTER(LinkArgs)]),
     "sdr_link_ber_c32": (c_int, [c_void_p, POINTER(LinkArgs)]),
     "sdr_link_sweep_c32": (c_int, [c_void_p, POINTER(SweepArgs)]),
+    "sdr_link_channel_c32": (c_int, [c_void_p, c_uint32, c_uint64, c_uint64, c_size_t, c_void_p]),
+    "sdr_link_chain_workspace": (c_int, [POINTER(ChainArgs), POINTER(c_uint64)]),
+    "sdr_link_chain_c32": (c_int, [c_void_p, POINTER(ChainArgs)]),
     "sdr_philox4x32_10": (c_int, [POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32)]),
     "sdr_pipe_create": (c_int, [c_int, POINTER(PipeConfig), POINTER(c_void_p)]),
     "sdr_pipe_acquire": (c_int, [c_void_p, POINTER(c_void_p)]),

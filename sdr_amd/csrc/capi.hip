@@ -339,6 +339,25 @@ int sdr_link_sweep_c32(sdr_ctx* ctx, const sdr_sweep_args* args)
     return link_sweep(ctx, *args);
 }
 
+int sdr_link_channel_c32(sdr_ctx* ctx, uint32_t n_fft, uint64_t seed, uint64_t first_set, size_t n_sets, void* d_chan)
+{
+    SDR_TRY(ensure_device(ctx));
+    return link_channel(ctx, n_fft, seed, first_set, n_sets, d_chan);
+}
+
+int sdr_link_chain_workspace(const sdr_chain_args* args, uint64_t* bytes)
+{
+    if (!args || !bytes) return fail(SDR_ERR_INVALID, "null argument");
+    return link_chain_workspace(*args, bytes);
+}
+
+int sdr_link_chain_c32(sdr_ctx* ctx, const sdr_chain_args* args)
+{
+    SDR_TRY(ensure_device(ctx));
+    if (!args) return fail(SDR_ERR_INVALID, "null args");
+    return link_chain(ctx, *args);
+}
+
 int sdr_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
 {
     if (!ctr || !key || !out) return fail(SDR_ERR_INVALID, "null pointer");

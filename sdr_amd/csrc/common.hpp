@@ -58,6 +58,11 @@ struct sdr_ctx {
     void* pinned = nullptr;
     size_t pinned_bytes = 0;
     hipEvent_t pinned_done = nullptr;
+    // second stream and hand-off events of the chunked link (link_chain): the generator of chunk i+1
+    // runs beside the demodulation of chunk i
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t chain_generated[2] = {nullptr, nullptr};
+    hipEvent_t chain_consumed[2] = {nullptr, nullptr};
     // kCounterSlots x 8 partial counters; kernels add into slot (workgroup id mod kCounterSlots),
     // fold_counters() sums them into the caller's eight and leaves them zero again.
     unsigned long long* counter_slots = nullptr;

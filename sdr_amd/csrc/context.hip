@@ -258,6 +258,11 @@ void sdr_destroy(sdr_ctx* ctx)
     for (auto& kv : ctx->twiddles) (void)hipFree(kv.second);
     for (auto& s : ctx->stage) if (s.ptr) (void)hipFree(s.ptr);
     if (ctx->counter_slots) (void)hipFree(ctx->counter_slots);
+    if (ctx->aux_stream) { (void)hipStreamSynchronize(ctx->aux_stream); (void)hipStreamDestroy(ctx->aux_stream); }
+    for (int i = 0; i < 2; ++i) {
+        if (ctx->chain_generated[i]) (void)hipEventDestroy(ctx->chain_generated[i]);
+        if (ctx->chain_consumed[i]) (void)hipEventDestroy(ctx->chain_consumed[i]);
+    }
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->pinned_done) (void)hipEventDestroy(ctx->pinned_done);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);

@@ -41,6 +41,9 @@ int copy_shape_launch(sdr_ctx* ctx, const void* d_rx, uint32_t n_fft, uint32_t c
 int link_generate(sdr_ctx* ctx, const sdr_link_args& a);
 int link_ber(sdr_ctx* ctx, const sdr_link_args& a);
 int link_sweep(sdr_ctx* ctx, const sdr_sweep_args& a);
+int link_channel(sdr_ctx* ctx, uint32_t n_fft, uint64_t seed, uint64_t first_set, size_t n_sets, void* d_chan);
+int link_chain_workspace(const sdr_chain_args& a, uint64_t* bytes);
+int link_chain(sdr_ctx* ctx, const sdr_chain_args& a);
 bool tx_fused_ok(size_t n_fft, size_t cp, const void* d_in, const void* d_out);
 int tx_fused_launch(sdr_ctx* ctx, const void* d_in, uint32_t n_fft, uint32_t cp, uint64_t n_sym, void* d_out);
 

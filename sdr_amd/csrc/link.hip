@@ -370,4 +370,150 @@ int link_sweep(sdr_ctx* ctx, const sdr_sweep_args& a)
                           reinterpret_cast<unsigned long long*>(a.d_counters));
 }
 
+namespace {
+
+__global__ void channel_kernel(uint32_t n_fft, uint64_t seed, uint64_t first_set, size_t n_sets, float2* __restrict__ chan)
+{
+    const size_t total = n_sets * n_fft;
+    for (size_t e = blockIdx.x * size_t(blockDim.x) + threadIdx.x; e < total; e += size_t(gridDim.x) * blockDim.x) {
+        const size_t s = e / n_fft;
+        chan[e] = chan_sample(seed, first_set + s, static_cast<uint32_t>(e - s * n_fft));
+    }
+}
+
+struct ChainLayout {
+    size_t rx[2], bits[2], chan[2], taps[2], wgt[2], llr, total;
+    uint64_t chunk, sets_per_chunk;
+};
+
+int chain_layout(const sdr_chain_args& a, ChainLayout& l)
+{
+    if (a.struct_size != sizeof(sdr_chain_args)) return fail(SDR_ERR_INVALID, "sdr_chain_args.struct_size %u != %zu", a.struct_size, sizeof(sdr_chain_args));
+    if (!valid_mod(static_cast<int>(a.mod))) return fail(SDR_ERR_INVALID, "unknown modulation %u", a.mod);
+    if (a.n_fft == 0 || !is_pow2(a.n_fft)) return fail(SDR_ERR_NOT_POW2, "%s", kPow2Message);
+    if (!rx_fused_supported(a.n_fft, a.mod) || a.cp % 2 != 0 || a.cp > a.n_fft) return fail(SDR_ERR_UNSUPPORTED, "the chunked link covers n_fft 64..8192 with an even cp <= n_fft");
+    if (a.sym_per_set == 0) return fail(SDR_ERR_INVALID, "sym_per_set must be >= 1");
+    if (a.chunk_symbols == 0 || a.chunk_symbols % a.sym_per_set != 0 || a.first_symbol % a.sym_per_set != 0)
+        return fail(SDR_ERR_INVALID, "chunk_symbols (%llu) and first_symbol (%llu) must be multiples of sym_per_set (%u)", static_cast<unsigned long long>(a.chunk_symbols),
+                    static_cast<unsigned long long>(a.first_symbol), a.sym_per_set);
+    l.chunk = a.chunk_symbols < a.n_sym ? a.chunk_symbols : ((a.n_sym + a.sym_per_set - 1) / a.sym_per_set) * a.sym_per_set;
+    if (l.chunk == 0) l.chunk = a.sym_per_set;
+    l.sets_per_chunk = l.chunk / a.sym_per_set;
+    auto up = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
+    size_t off = 0;
+    for (int b = 0; b < 2; ++b) {
+        l.rx[b] = off; off += up(l.chunk * (size_t(a.n_fft) + a.cp) * sizeof(float2));
+        l.bits[b] = off; off += up(l.chunk * a.n_fft * a.mod / 8);
+        l.chan[b] = off; off += up(l.sets_per_chunk * a.n_fft * sizeof(float2));
+        l.taps[b] = off; off += up(l.sets_per_chunk * a.n_fft * sizeof(float2));
+        l.wgt[b] = off; off += up(l.sets_per_chunk * a.n_fft * sizeof(float));
+    }
+    l.llr = off;
+    if (!a.no_llr) off += up(l.chunk * a.n_fft * a.mod * sizeof(float));
+    l.total = off;
+    return SDR_OK;
+}
+
+// runs `fn` with the context enqueueing on `s`
+struct StreamSwap {
+    sdr_ctx* ctx; hipStream_t saved;
+    StreamSwap(sdr_ctx* c, hipStream_t s) : ctx(c), saved(c->stream) { c->stream = s; }
+    ~StreamSwap() { ctx->stream = saved; }
+};
+
+} // namespace
+
+int link_channel(sdr_ctx* ctx, uint32_t n_fft, uint64_t seed, uint64_t first_set, size_t n_sets, void* d_chan)
+{
+    if (n_fft == 0 || n_sets == 0) return SDR_OK;
+    if (!d_chan) return fail(SDR_ERR_INVALID, "null d_chan");
+    hipLaunchKernelGGL(channel_kernel, dim3(grid_for(ctx, n_sets * n_fft)), dim3(kThreads), 0, ctx->stream, n_fft, seed, first_set, n_sets, static_cast<float2*>(d_chan));
+    SDR_HIP(hipGetLastError());
+    return SDR_OK;
+}
+
+int link_chain_workspace(const sdr_chain_args& a, uint64_t* bytes)
+{
+    ChainLayout l;
+    SDR_TRY(chain_layout(a, l));
+    *bytes = l.total;
+    return SDR_OK;
+}
+
+int link_chain(sdr_ctx* ctx, const sdr_chain_args& a)
+{
+    ChainLayout l;
+    SDR_TRY(chain_layout(a, l));
+    if (!a.d_counters) return fail(SDR_ERR_INVALID, "null d_counters");
+    if (a.n_sym == 0) return SDR_OK;
+    if (!a.d_workspace || a.workspace_bytes < l.total) return fail(SDR_ERR_INVALID, "workspace of %llu bytes, %zu needed", static_cast<unsigned long long>(a.workspace_bytes), l.total);
+    if (reinterpret_cast<uintptr_t>(a.d_workspace) % 256 != 0) return fail(SDR_ERR_INVALID, "workspace must be 256-byte aligned");
+    if (!ctx->aux_stream) {
+        // SDR_CHAIN_PRIORITY (measurement knob): priority of the generator stream relative to the context's (-1 high, 1 low, 0 default)
+        static const int prio = [] { const char* v = getenv("SDR_CHAIN_PRIORITY"); return v ? atoi(v) : 0; }();
+        int lo = 0, hi = 0;
+        SDR_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));          // lo = least, hi = greatest (numerically smaller)
+        const int p = prio < 0 ? hi : prio > 0 ? lo : 0;
+        SDR_HIP(hipStreamCreateWithPriority(&ctx->aux_stream, hipStreamNonBlocking, p));
+    }
+    static const bool serial = getenv("SDR_CHAIN_SERIAL") != nullptr;      // measurement knob: generator on the context's own stream
+    hipStream_t gen_stream = serial ? ctx->stream : ctx->aux_stream;
+    for (int b = 0; b < 2; ++b) {
+        if (!ctx->chain_generated[b]) SDR_HIP(hipEventCreateWithFlags(&ctx->chain_generated[b], hipEventDisableTiming));
+        if (!ctx->chain_consumed[b]) SDR_HIP(hipEventCreateWithFlags(&ctx->chain_consumed[b], hipEventDisableTiming));
+    }
+    // tables are created synchronously on first use: do it before the two streams start
+    const void* tw = nullptr;
+    SDR_TRY(get_twiddles(ctx, a.n_fft, false, false, &tw));
+    SDR_TRY(get_twiddles(ctx, a.n_fft, true, false, &tw));
+    if (a.d_counters) { unsigned long long* slots = nullptr; SDR_TRY(get_counter_slots(ctx, &slots)); }
+    unsigned char* ws = static_cast<unsigned char*>(a.d_workspace);
+    hipStream_t main_stream = ctx->stream;
+    // the generator stream starts behind whatever the caller has queued on the context's stream
+    // (the workspace may still be in use there), via an event of its own
+    SDR_HIP(hipEventRecord(ctx->chain_consumed[0], main_stream));
+    SDR_HIP(hipStreamWaitEvent(gen_stream, ctx->chain_consumed[0], 0));
+    const uint64_t n_chunks = (a.n_sym + l.chunk - 1) / l.chunk;
+    auto generate = [&](uint64_t c) -> int {
+        const int b = static_cast<int>(c & 1);
+        const uint64_t done = c * l.chunk;
+        const uint64_t now = a.n_sym - done < l.chunk ? a.n_sym - done : l.chunk;
+        const uint64_t sets = (now + a.sym_per_set - 1) / a.sym_per_set;
+        const uint64_t first_set = (a.first_symbol + done) / a.sym_per_set;
+        StreamSwap swap(ctx, gen_stream);
+        if (c >= 2) SDR_HIP(hipStreamWaitEvent(gen_stream, ctx->chain_consumed[b], 0));     // buffer b was read by chunk c-2
+        SDR_TRY(link_channel(ctx, a.n_fft, a.seed, first_set, sets, ws + l.chan[b]));
+        SDR_TRY(zf_taps_dev(ctx, static_cast<int>(a.mod), ws + l.chan[b], sets * a.n_fft, a.inv_n0, ws + l.taps[b], reinterpret_cast<float*>(ws + l.wgt[b])));
+        sdr_link_args g = {};
+        g.struct_size = sizeof(sdr_link_args);
+        g.n_fft = a.n_fft; g.cp = a.cp; g.mod = a.mod; g.seed = a.seed;
+        g.first_symbol = a.first_symbol + done; g.n_sym = now; g.sym_per_set = a.sym_per_set; g.sigma = a.sigma;
+        g.d_chan = ws + l.chan[b]; g.d_rx = ws + l.rx[b]; g.d_tx_bits = ws + l.bits[b];
+        SDR_TRY(link_generate(ctx, g));
+        SDR_HIP(hipEventRecord(ctx->chain_generated[b], gen_stream));
+        return SDR_OK;
+    };
+    SDR_TRY(generate(0));
+    for (uint64_t c = 0; c < n_chunks; ++c) {
+        const int b = static_cast<int>(c & 1);
+        if (c + 1 < n_chunks) SDR_TRY(generate(c + 1));          // queued before the demodulation of chunk c: runs beside it
+        const uint64_t done = c * l.chunk;
+        const uint64_t now = a.n_sym - done < l.chunk ? a.n_sym - done : l.chunk;
+        SDR_HIP(hipStreamWaitEvent(main_stream, ctx->chain_generated[b], 0));
+        sdr_demod_args d = {};
+        d.struct_size = sizeof(sdr_demod_args);
+        d.n_fft = a.n_fft; d.cp = a.cp; d.mod = a.mod; d.n_sym = now; d.sym_per_set = a.sym_per_set;
+        d.d_rx = ws + l.rx[b];
+        d.d_eq = ws + l.taps[b];
+        d.d_llr_weight = reinterpret_cast<const float*>(ws + l.wgt[b]);
+        d.d_llr = a.no_llr ? nullptr : reinterpret_cast<float*>(ws + l.llr);
+        d.d_ref_hard = ws + l.bits[b];
+        d.d_counters = a.d_counters;
+        SDR_TRY(rx_fused_launch(ctx, d));
+        SDR_HIP(hipEventRecord(ctx->chain_consumed[b], main_stream));
+    }
+    if (a.d_llr_chunk) *a.d_llr_chunk = a.no_llr ? nullptr : reinterpret_cast<float*>(ws + l.llr);
+    return SDR_OK;
+}
+
 } // namespace sdr

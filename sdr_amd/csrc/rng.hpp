@@ -12,6 +12,7 @@ namespace sdr {
 constexpr uint32_t kStreamTx = 0x54580000u;      // transmitted constellation indices
 constexpr uint32_t kStreamNoise = 0x4E5A0000u;   // noise on payload samples
 constexpr uint32_t kStreamCp = 0x43500000u;      // noise on cyclic-prefix samples
+constexpr uint32_t kStreamChan = 0x43480000u;    // channel realisations (one per set of symbols)
 
 struct Philox4 { uint32_t v[4]; };
 
@@ -128,6 +129,14 @@ __device__ inline float2 cp_noise(uint64_t seed, uint64_t g, uint32_t cidx, floa
     const Philox4 b = philox4x32_10(cidx, static_cast<uint32_t>(g), static_cast<uint32_t>(g >> 32), kStreamCp,
                                     static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32));
     return gaussian_pair(b.v[0], b.v[1], sigma);
+}
+
+// Channel coefficient of subcarrier k in set `set`: unit-variance complex Gaussian.
+__device__ inline float2 chan_sample(uint64_t seed, uint64_t set, uint32_t k)
+{
+    const Philox4 b = philox4x32_10(k, static_cast<uint32_t>(set), static_cast<uint32_t>(set >> 32), kStreamChan,
+                                    static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32));
+    return gaussian_pair(b.v[0], b.v[1], 0.70710678f);
 }
 
 } // namespace sdr

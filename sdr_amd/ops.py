@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 from . import capi
-from .capi import DemodArgs, LinkArgs, SweepArgs, SweepPoint, check
+from .capi import ChainArgs, DemodArgs, LinkArgs, SweepArgs, SweepPoint, check
 
 MODS = {"bpsk": 1, "qpsk": 2, "16qam": 4, "64qam": 6, "256qam": 8, "1024qam": 10}
 
@@ -287,3 +287,51 @@ class Context:
         a.d_counters = counters.data_ptr()
         check(self.lib.sdr_link_sweep_c32(self._h, ctypes.byref(a)))
         return counters
+
+    def link_channel(self, n_fft: int, seed: int, first_set: int, n_sets: int) -> torch.Tensor:
+        """sdr_link_channel_c32: unit-variance complex Gaussian channel realisations, (n_sets, n_fft)."""
+        chan = torch.empty((n_sets, n_fft), dtype=torch.complex64, device=self.torch_device)
+        check(self.lib.sdr_link_channel_c32(self._h, n_fft, seed, first_set, n_sets, _ptr(chan)))
+        return chan
+
+    def _chain_args(self, n_fft, cp, mod, seed, first_symbol, n_sym, chunk_symbols, sym_per_set, sigma, inv_n0, want_llr) -> ChainArgs:
+        a = ChainArgs()
+        a.struct_size = ctypes.sizeof(ChainArgs)
+        a.n_fft, a.cp, a.mod = n_fft, cp, mod_bits(mod)
+        a.seed, a.first_symbol, a.n_sym, a.chunk_symbols = seed, first_symbol, n_sym, chunk_symbols
+        a.sym_per_set, a.no_llr = sym_per_set, 0 if want_llr else 1
+        a.sigma, a.inv_n0 = float(sigma), float(inv_n0)
+        return a
+
+    def link_chain_workspace(self, n_fft, cp, mod, n_sym, chunk_symbols, sym_per_set, want_llr=True) -> int:
+        a = self._chain_args(n_fft, cp, mod, 0, 0, n_sym, chunk_symbols, sym_per_set, 0.0, 0.0, want_llr)
+        n = ctypes.c_uint64()
+        check(self.lib.sdr_link_chain_workspace(ctypes.byref(a), ctypes.byref(n)))
+        return int(n.value)
+
+    def link_chain(self, n_fft: int, cp: int, mod, seed: int, first_symbol: int, n_sym: int, chunk_symbols: int, sym_per_set: int,
+                   sigma: float, inv_n0: float, *, workspace: Optional[torch.Tensor] = None, counters: Optional[torch.Tensor] = None, want_llr: bool = True):
+        """sdr_link_chain_c32: channel -> taps -> generate -> equalised demodulation -> counters over
+        n_sym symbols in resident chunks that reuse `workspace` (uint8 tensor; allocated when None).
+        Returns (counters, llr view of the LAST chunk or None, workspace)."""
+        need = self.link_chain_workspace(n_fft, cp, mod, n_sym, chunk_symbols, sym_per_set, want_llr)
+        if workspace is None:
+            workspace = torch.empty(need, dtype=torch.uint8, device=self.torch_device)
+        _need(workspace, torch.uint8, "workspace")
+        if counters is None:
+            counters = torch.zeros(8, dtype=torch.int64, device=self.torch_device)
+        _need(counters, torch.int64, "counters", 8)
+        a = self._chain_args(n_fft, cp, mod, seed, first_symbol, n_sym, chunk_symbols, sym_per_set, sigma, inv_n0, want_llr)
+        a.d_workspace, a.workspace_bytes, a.d_counters = workspace.data_ptr(), workspace.numel(), counters.data_ptr()
+        where = ctypes.c_void_p()
+        a.d_llr_chunk = ctypes.pointer(where)
+        check(self.lib.sdr_link_chain_c32(self._h, ctypes.byref(a)))
+        llr = None
+        if want_llr and where.value:
+            bps = mod_bits(mod)
+            chunk = min(chunk_symbols, -(-n_sym // sym_per_set) * sym_per_set)
+            last = n_sym - ((n_sym - 1) // chunk) * chunk
+            off = where.value - workspace.data_ptr()
+            llr = workspace[off: off + last * n_fft * bps * 4].view(torch.float32).view(last, n_fft, bps)
+        return counters, llr, workspace
+
