@@ -283,7 +283,22 @@ struct NoLateWork { __device__ __forceinline__ void operator()() const {} };
 // `late` runs between the two barriers of the second exchange (3-pass plans): the place where
 // kernels that are short of registers request what only the last pass and the epilogue need
 // (last-pass twiddles, equaliser taps), so that it is not live across the first two passes.
-template <int LOG2N, bool CONJ = false, typename Late = NoLateWork, int LATE_AT = 1>
+// WAVE_SYNC: the symbol lives in ONE wave of a workgroup that holds several symbols (RxShape GROUP):
+// its exchanges need program order inside the wave only (LDS serves a wave's instructions in order),
+// not a barrier over the other symbols' waves.
+template <bool WAVE_SYNC>
+__device__ __forceinline__ void symbol_sync()
+{
+    if constexpr (WAVE_SYNC) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
+
+template <int LOG2N, bool CONJ = false, typename Late = NoLateWork, int LATE_AT = 1, bool WAVE_SYNC = false>
 __device__ __forceinline__ void fft_run(float2 (&x)[PlanOps<LOG2N>::kE], unsigned char* lds_data, const FftAddr<LOG2N>& a, const FftTwiddles<LOG2N>& w, Late&& late = Late{})
 {
     using O = PlanOps<LOG2N>;
@@ -300,7 +315,7 @@ __device__ __forceinline__ void fft_run(float2 (&x)[PlanOps<LOG2N>::kE], unsigne
     });
     static_for<E>([&](auto M) { constexpr int m = M; *reinterpret_cast<float2*>(lds_data + a.wr0 + O::reg_addr(0, 0, m)) = x[m]; });
     if constexpr (LATE_AT == 0) late();
-    __syncthreads();
+    symbol_sync<WAVE_SYNC>();
     static_for<E>([&](auto M) { constexpr int m = M; x[m] = *reinterpret_cast<const float2*>(lds_data + a.rd0 + O::reg_addr(0, 1, m)); });
     if constexpr (O::kPasses == 3) {
         static_for<P::kR[1]>([&](auto S) {
@@ -312,10 +327,10 @@ __device__ __forceinline__ void fft_run(float2 (&x)[PlanOps<LOG2N>::kE], unsigne
                 bfly<CONJ>(x[m0], x[m1], w.mid[(1 << c) - 1 - O::kMidFirst + jm + a.mid_jt]);
             });
         });
-        __syncthreads();   // all reads of exchange 0 done before the region is rewritten
+        symbol_sync<WAVE_SYNC>();   // all reads of exchange 0 done before the region is rewritten
         if constexpr (LATE_AT == 1) late();
         static_for<E>([&](auto M) { constexpr int m = M; *reinterpret_cast<float2*>(lds_data + a.wr1 + O::reg_addr(1, 1, m)) = x[m]; });
-        __syncthreads();
+        symbol_sync<WAVE_SYNC>();
         static_for<E>([&](auto M) { constexpr int m = M; x[m] = *reinterpret_cast<const float2*>(lds_data + a.rd1 + O::reg_addr(1, 2, m)); });
     }
     static_for<P::kR[LAST]>([&](auto S) {
@@ -398,15 +413,23 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 
 // Compile-time shape of one instantiation: LDS layout, control structure and the bounds on the
 // waves per SIMD handed to the compiler.
-template <int LOG2N, int MI, int MQ, bool FULL, bool EQ, bool HARDONLY>
+// GROUP > 1 (tap-holding LLR-only variant at N = 1024 / 2048): the workgroup is GROUP independent
+// symbols, each run by its own kWG threads exactly like a one-symbol workgroup, that belong to ONE
+// tap set (the host picks this variant when sym_per_set is a multiple of GROUP) and share its taps and
+// weights through LDS.  The taps then cross L2 -> CU once per GROUP symbols as two loads per thread,
+// instead of once per two symbols as sixteen loads per thread into 48 held registers: that path, not
+// the arithmetic, is what the tap-holding variant loses against the plain one.
+template <int LOG2N, int MI, int MQ, bool FULL, bool EQ, bool HARDONLY, int GROUP = 1>
 struct RxShape {
     using O = PlanOps<LOG2N>;
     static constexpr int N = O::kN, SPW = O::kSPW;
     static constexpr int BPS = MI + MQ;
     static constexpr bool DEMAP = BPS > 0;
     static_assert(!(HARDONLY && (FULL || EQ || !DEMAP)), "HARDONLY is a variant of its own");
+    static_assert(GROUP == 1 || (EQ && !FULL && !HARDONLY && DEMAP && O::kSPW == 1 && O::kWG * GROUP <= 1024), "grouped symbols: tap-holding LLR-only variant, one symbol per kWG threads");
+    static constexpr int WG_THREADS = O::kWG * GROUP;
     static constexpr int SYM_BYTES = O::max_sym_bytes();
-    static constexpr int DATA_BYTES = SYM_BYTES * SPW;
+    static constexpr int DATA_BYTES = SYM_BYTES * SPW * GROUP;
     static constexpr int TW_BYTES = O::kMidCount * 8;
     using idx_t = std::conditional_t<(BPS > 8), uint16_t, uint8_t>;      // one hard decision
     static constexpr bool HARD_PATH = (FULL || HARDONLY) && DEMAP;       // hard decisions pass through LDS and are packed
@@ -430,10 +453,14 @@ struct RxShape {
 #ifdef SDR_NO_STG_ALIAS
     static constexpr bool STG_ALIAS = false;
 #else
-    static constexpr bool STG_ALIAS = STAGE && STG_BYTES <= DATA_BYTES && (O::kWG == 64 || LOG2N >= SDR_ALIAS_FROM || FULL);
+    static constexpr bool STG_ALIAS = STAGE && STG_BYTES <= SYM_BYTES * SPW && (O::kWG == 64 || LOG2N >= SDR_ALIAS_FROM || FULL || GROUP > 1);
 #endif
+    static_assert(GROUP == 1 || !STAGE || STG_ALIAS, "grouped symbols stage their LLRs inside their own exchange region");
     static constexpr int STG_OFF = STG_ALIAS ? 0 : (DATA_BYTES + TW_BYTES + IDX_BYTES + REF_BYTES + 15) & ~15;
-    static constexpr int LDS_USED = (STG_ALIAS ? DATA_BYTES + TW_BYTES + IDX_BYTES + REF_BYTES : STG_OFF + STG_BYTES) + 16;
+    // shared taps (8 bytes) and weights (4 bytes) of one set, GROUP > 1 only
+    static constexpr int TAPS_OFF = (DATA_BYTES + TW_BYTES + IDX_BYTES + REF_BYTES + 15) & ~15;
+    static constexpr int TAPS_BYTES = GROUP > 1 ? 12 * N : 0;
+    static constexpr int LDS_USED = GROUP > 1 ? TAPS_OFF + TAPS_BYTES + 16 : (STG_ALIAS ? DATA_BYTES + TW_BYTES + IDX_BYTES + REF_BYTES : STG_OFF + STG_BYTES) + 16;
     // Resident workgroups per CU of the LLR-only kernels at N <= 1024.  These kernels are bound by the
     // memory system, and the memory system runs a 1 : bps/2 read/write mix FASTER with fewer symbols
     // in flight (a copy of this shape: 5.4 TB/s at 16 waves per CU, 6.0 at 4-5, tools/membench6/7),
@@ -472,7 +499,7 @@ struct RxShape {
     // beside LLRs: 63 -> 68 %; N = 8192: 56 -> 71 %).  Counting variants then end every symbol with
     // four atomics per wave on the 1024 counter slots, which measured no slower than runs of eight.
     // (The name is historical: the run of two is written out, see `process` in the kernel.)
-    static constexpr bool LOOP = EQ && !LATE_TAPS && !SDR_EQ_NOLOOP;
+    static constexpr bool LOOP = EQ && !LATE_TAPS && !SDR_EQ_NOLOOP && GROUP == 1;
 
     // Waves per SIMD.  Lower bound = register budget: the tap-holding and FULL variants must not
     // drift to 256+ registers (one wave per SIMD); at N = 8192 (E = 32) FULL variants are held to
@@ -481,12 +508,12 @@ struct RxShape {
     // allow more per SIMD than that, the dispatcher fills the SIMDs unevenly and a two- or four-wave
     // workgroup loses 5-8 points (N = 2048 / 64-QAM at 114 registers: 65 %; the same code padded to
     // 168 registers, i.e. three waves per SIMD: 73 %).  The compiler pads the allocation for it.
-    static constexpr int WAVES_PER_WG = O::kWG / 64;
+    static constexpr int WAVES_PER_WG = WG_THREADS / 64;
     static constexpr int LDS_WAVES = (160 * 1024 / ((LDS_BYTES + 511) & ~511)) * WAVES_PER_WG;
 #ifdef SDR_WPE
     static constexpr int MIN_WAVES = SDR_WPE, MAX_WAVES = SDR_WPE;
 #else
-    static constexpr int MIN_WAVES = LOG2N >= 13 ? ((FULL || EQ || HARDONLY) ? 1 : 2) : FULL ? SDR_EQ_WPE : EQ ? (LATE_TAPS ? 3 : SDR_EQ_WPE) : 1;
+    static constexpr int MIN_WAVES = GROUP > 1 ? 1 : LOG2N >= 13 ? ((FULL || EQ || HARDONLY) ? 1 : 2) : FULL ? SDR_EQ_WPE : EQ ? (LATE_TAPS ? 3 : SDR_EQ_WPE) : 1;
     static constexpr int even_share() { const int w = (LDS_WAVES + 3) / 4; return w < 1 ? 1 : w > 8 ? 8 : w; }
 #ifdef SDR_NO_MAX_WAVES
     static constexpr int MAX_WAVES = 8;
@@ -501,14 +528,14 @@ struct RxShape {
 // set, or requested per symbol: RxShape::LATE_TAPS; costs registers, hence a separate instantiation).
 // HARDONLY: packed hard decisions are the only output (the reference's own chain ofdm::rx ->
 // from_constl, lib/inc/ofdm.hpp:37-43 + modulation.hpp:96-112): no LLR arithmetic at all.
-template <int LOG2N, int MI, int MQ, bool FULL, bool EQ, bool HARDONLY = false>
-__global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
-    __attribute__((amdgpu_waves_per_eu(RxShape<LOG2N, MI, MQ, FULL, EQ, HARDONLY>::MIN_WAVES, RxShape<LOG2N, MI, MQ, FULL, EQ, HARDONLY>::MAX_WAVES)))
+template <int LOG2N, int MI, int MQ, bool FULL, bool EQ, bool HARDONLY = false, int GROUP = 1>
+__global__ void __launch_bounds__(PlanOps<LOG2N>::kWG * GROUP)
+    __attribute__((amdgpu_waves_per_eu(RxShape<LOG2N, MI, MQ, FULL, EQ, HARDONLY, GROUP>::MIN_WAVES, RxShape<LOG2N, MI, MQ, FULL, EQ, HARDONLY, GROUP>::MAX_WAVES)))
     rx_fused_kernel(const RxParams p)
 {
     using O = PlanOps<LOG2N>;
     using P = typename O::P;
-    using S = RxShape<LOG2N, MI, MQ, FULL, EQ, HARDONLY>;
+    using S = RxShape<LOG2N, MI, MQ, FULL, EQ, HARDONLY, GROUP>;
     using idx_t = typename S::idx_t;
     constexpr int N = O::kN, E = O::kE, TPS = O::kTPS, SPW = O::kSPW, LAST = O::kLast;
     constexpr int BPS = S::BPS;
@@ -522,9 +549,13 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
     [[maybe_unused]] idx_t* lds_idx = reinterpret_cast<idx_t*>(lds + DATA_BYTES + TW_BYTES);
     [[maybe_unused]] unsigned char* lds_ref = lds + DATA_BYTES + TW_BYTES + IDX_BYTES;
 
-    const int tid = threadIdx.x;
-    const int slot = SPW == 1 ? 0 : tid / TPS;
+    // GROUP > 1: `tid` is the thread's id inside its symbol's kWG threads, `gslot` the symbol's place in the workgroup
+    const int gslot = GROUP > 1 ? static_cast<int>(threadIdx.x) / O::kWG : 0;
+    const int tid = GROUP > 1 ? static_cast<int>(threadIdx.x) % O::kWG : static_cast<int>(threadIdx.x);
+    const int slot = GROUP > 1 ? gslot : SPW == 1 ? 0 : tid / TPS;        // exchange region of the thread's symbol
     const int t = SPW == 1 ? tid : tid % TPS;
+    constexpr int SPG = SPW * GROUP;                                      // symbols per workgroup
+    constexpr bool WAVE_SYNC = GROUP > 1 && O::kWG == 64;
 
     // ---- per-workgroup set-up: addresses and twiddles ----
     FftAddr<LOG2N> addr;
@@ -536,13 +567,13 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
 
     unsigned long long c_bit = 0, c_sym = 0, c_abs = 0, c_sign = 0;
 
-    const unsigned long long n_groups = (p.n_sym + SPW - 1) / SPW;
+    const unsigned long long n_groups = (p.n_sym + SPG - 1) / SPG;
     const size_t in_stride = static_cast<size_t>(N) + p.cp;
     if constexpr (O::kMidCount > 0) __syncthreads();
 
     // global load of one symbol into registers: CP skipped, bit reversal folded into the index
     auto load_symbol = [&](unsigned long long grp_, float2 (&dst)[E]) {
-        unsigned long long s_ = grp_ * SPW + slot;
+        unsigned long long s_ = grp_ * SPG + slot;
         if (s_ >= p.n_sym) s_ = p.n_sym - 1;
         const float2* src = p.rx + s_ * in_stride + p.cp + in_thread;
         constexpr int GI = O::kGroupIn;
@@ -583,16 +614,16 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
     const unsigned long long grp_begin = wg * p.groups_per_wg;
     const unsigned long long grp_end = (grp_begin + p.groups_per_wg < n_groups) ? grp_begin + p.groups_per_wg : n_groups;
     float2 x[E];
-    constexpr bool PREFETCH_TAPS = EQ && DEMAP;
-    [[maybe_unused]] float2 eqv[EQ ? E : 1];
-    [[maybe_unused]] float wv[EQ ? E : 1];
+    constexpr bool PREFETCH_TAPS = EQ && DEMAP && GROUP == 1;
+    [[maybe_unused]] float2 eqv[PREFETCH_TAPS ? E : 1];
+    [[maybe_unused]] float wv[PREFETCH_TAPS ? E : 1];
     [[maybe_unused]] size_t held_set = ~static_cast<size_t>(0);     // set whose taps the registers hold
     if (grp_begin >= grp_end) return;      // uniform over the workgroup
     // One symbol group, as a body that the tap-holding variants run twice: written out, because a
     // loop around barriers does not unroll and anything hoisted out of a rolled loop costs
     // registers the transform needs (243 -> 180 at N = 2048).
     auto process = [&](const unsigned long long grp) __attribute__((always_inline)) {
-        unsigned long long sym = grp * SPW + slot;
+        unsigned long long sym = grp * SPG + slot;
         const bool active = sym < p.n_sym;
         if (!active) sym = p.n_sym - 1;
 
@@ -670,8 +701,43 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
             });
         }
 
+        // GROUP > 1: the workgroup's threads fetch the set's taps and weights once, two or three
+        // 16-byte loads per thread requested ahead of the samples, and park them in LDS for the epilogues
+        // of all GROUP symbols (index clamped: surplus threads repeat the last vector).
+        constexpr int WGT = S::WG_THREADS;
+        constexpr int NE = (N / 2 + WGT - 1) / WGT;        // float4 = two taps
+        constexpr int NW = (N / 4 + WGT - 1) / WGT;        // float4 = four weights
+        [[maybe_unused]] float4 tap_e[GROUP > 1 ? NE : 1];
+        [[maybe_unused]] float4 tap_w[GROUP > 1 ? NW : 1];
+        if constexpr (GROUP > 1) {
+            static_assert(O::kGroupOut == 2, "grouped symbols read their taps as pairs of adjacent bins");
+            const size_t gset = p.sym_per_set ? static_cast<size_t>((grp * SPG) / p.sym_per_set) : 0;
+            const float2* dummy = p.rx + static_cast<size_t>(sym) * in_stride;      // >= N readable float2, 16-byte aligned
+            const float4* e4 = reinterpret_cast<const float4*>(p.eq ? p.eq + gset * N : dummy);
+            const float4* w4 = reinterpret_cast<const float4*>(p.wgt ? p.wgt + gset * N : reinterpret_cast<const float*>(dummy));
+            const int wtid = static_cast<int>(threadIdx.x);
+#ifdef SDR_EQ_NOLOAD    // experiment: the grouped structure without any tap traffic
+            static_for<NE>([&](auto J) { constexpr int j = J; tap_e[j] = make_float4(p.w0, p.inorm, p.w0, p.inorm); });
+            static_for<NW>([&](auto J) { constexpr int j = J; tap_w[j] = make_float4(p.w0, p.w0, p.w0, p.w0); });
+            (void)e4; (void)w4; (void)wtid;
+#else
+            static_for<NE>([&](auto J) { constexpr int j = J; int i = j * WGT + wtid; if (i > N / 2 - 1) i = N / 2 - 1; tap_e[j] = e4[i]; });
+            static_for<NW>([&](auto J) { constexpr int j = J; int i = j * WGT + wtid; if (i > N / 4 - 1) i = N / 4 - 1; tap_w[j] = w4[i]; });
+#endif
+        }
+
         // ---- pass 0 ----
         load_symbol(grp, x);
+        if constexpr (GROUP > 1) {
+            float4* lds_e = reinterpret_cast<float4*>(lds + S::TAPS_OFF);
+            float4* lds_w = reinterpret_cast<float4*>(lds + S::TAPS_OFF + 8 * N);
+            const int wtid = static_cast<int>(threadIdx.x);
+            static_for<NE>([&](auto J) { constexpr int j = J; int i = j * WGT + wtid; if (i > N / 2 - 1) i = N / 2 - 1; lds_e[i] = tap_e[j]; });
+            static_for<NW>([&](auto J) { constexpr int j = J; int i = j * WGT + wtid; if (i > N / 4 - 1) i = N / 4 - 1; lds_w[i] = tap_w[j]; });
+            // The workgroup's only barrier sits HERE, while the samples are still on their way: from now
+            // on the GROUP symbols run independently (one-wave symbols: no further barrier at all).
+            __syncthreads();
+        }
 #ifdef SDR_EQ_TAPS_AFTER     // experiment: taps requested behind the samples
         if constexpr (PREFETCH_TAPS && !LATE_TAPS) {
             if (tap_set != held_set) {
@@ -693,10 +759,11 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
             auto late = [&]() { load_taps(); };
             fft_run<LOG2N, false, decltype(late), SDR_LATE_AT>(x, lds_data, addr, tw, std::move(late));
         } else {
-            fft_run<LOG2N>(x, lds_data, addr, tw);
+            fft_run<LOG2N, false, NoLateWork, 1, WAVE_SYNC>(x, lds_data, addr, tw);
         }
 
-        if constexpr (STG_ALIAS && O::kWG > 64) __syncthreads();   // every wave is past its last exchange read
+        // every wave is past its last exchange read (staging strips alias it); GROUP > 1: the shared taps are in LDS
+        if constexpr (STG_ALIAS && O::kWG > 64) __syncthreads();
 
         // ---- epilogue: bins are in natural order, k = reg_pos(LAST, m) | pos_last ----
         constexpr int GO = O::kGroupOut;   // adjacent bins held in registers m = GO*h + (0..GO-1)
@@ -728,6 +795,7 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
                         if (p.eq) {
                             float2 gk;
                             if constexpr (PREFETCH_TAPS) gk = eqv[h * GO + g];
+                            else if constexpr (GROUP > 1) gk = reinterpret_cast<const float2*>(lds + S::TAPS_OFF)[k + g];
                             else gk = p.eq[tap_set * N + k + g];
                             const float er = y.x * gk.x - y.y * gk.y;
                             const float ei = y.x * gk.y + y.y * gk.x;
@@ -735,6 +803,7 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
                         }
                         if (p.wgt) {
                             if constexpr (PREFETCH_TAPS) w = wv[h * GO + g];
+                            else if constexpr (GROUP > 1) w = reinterpret_cast<const float*>(lds + S::TAPS_OFF + 8 * N)[k + g];
                             else w = p.wgt[tap_set * N + k + g];
                         }
                     }
@@ -751,7 +820,7 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
                         constexpr int NV = 64 * CHUNK / VW;                      // vectors per wave and block
                         constexpr int VPL = CHUNK / VW;                          // vectors per lane (padded strips)
                         const int lane = tid & 63;
-                        float* stg = reinterpret_cast<float*>(lds + STG_OFF + (tid >> 6) * STG_WAVE_BYTES);
+                        float* stg = reinterpret_cast<float*>(lds + STG_OFF + (GROUP > 1 ? gslot * SYM_BYTES : 0) + (tid >> 6) * STG_WAVE_BYTES);
                         store_floats<CHUNK>(stg + lane * (STG_STRIDE / 4), l);
                         __builtin_amdgcn_wave_barrier();
                         constexpr int gbits = O::kLogE - P::kR[LAST];
@@ -896,23 +965,24 @@ struct RxTuning {
 RxTuning& rx_tuning_mutable();      // rx_fused.hip
 inline const RxTuning& rx_tuning() { return rx_tuning_mutable(); }
 
-template <int LOG2N, int MI, int MQ, bool FULL, bool EQ, bool HARDONLY = false>
+template <int LOG2N, int MI, int MQ, bool FULL, bool EQ, bool HARDONLY = false, int GROUP = 1>
 int launch_rx_fused(sdr_ctx* ctx, const RxParams& p)
 {
     using O = PlanOps<LOG2N>;
-    auto kern = rx_fused_kernel<LOG2N, MI, MQ, FULL, EQ, HARDONLY>;
+    using S = RxShape<LOG2N, MI, MQ, FULL, EQ, HARDONLY, GROUP>;
+    auto kern = rx_fused_kernel<LOG2N, MI, MQ, FULL, EQ, HARDONLY, GROUP>;
     const RxTuning& tune = rx_tuning();
-    const unsigned long long n_groups = (p.n_sym + O::kSPW - 1) / O::kSPW;
+    const unsigned long long n_groups = (p.n_sym + O::kSPW * GROUP - 1) / (O::kSPW * GROUP);
     // One symbol group per workgroup (with the XCD-aware order: +1.5 to +5 points over runs of two
     // at N = 512 ... 4096, and far better than a resident grid striding over the batch; the
     // per-workgroup twiddle set-up is cheap, the finer grain balances better).  The tap-holding
     // variants take two, reloading their taps once per run (65 % against 61 %).
-    const unsigned long long per_wg = RxShape<LOG2N, MI, MQ, FULL, EQ, HARDONLY>::LOOP ? 2 : 1;
+    const unsigned long long per_wg = S::LOOP ? 2 : 1;
     if (tune.debug) {
         int nb = 0;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, O::kWG, static_cast<size_t>(tune.lds_pad > 0 ? tune.lds_pad : 0));
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, S::WG_THREADS, static_cast<size_t>(tune.lds_pad > 0 ? tune.lds_pad : 0));
         if (e != hipSuccess) return fail_hip(e, "hipOccupancyMaxActiveBlocksPerMultiprocessor");
-        fprintf(stderr, "[sdr] rx_fused<%d,%d,%d,%d,%d,%d>: %d threads/WG, %d WG/CU, %d CUs\n", LOG2N, MI, MQ, int(FULL), int(EQ), int(HARDONLY), O::kWG, nb, ctx->num_cu);
+        fprintf(stderr, "[sdr] rx_fused<%d,%d,%d,%d,%d,%d,%d>: %d threads/WG, %d WG/CU, %d CUs\n", LOG2N, MI, MQ, int(FULL), int(EQ), int(HARDONLY), GROUP, S::WG_THREADS, nb, ctx->num_cu);
     }
     const unsigned long long blocks = (n_groups + per_wg - 1) / per_wg;
     if (blocks > 0x7FFFFFFFull) return fail(SDR_ERR_UNSUPPORTED, "batch too large for one launch");
@@ -921,7 +991,7 @@ int launch_rx_fused(sdr_ctx* ctx, const RxParams& p)
     // never wider than the grid: a batch smaller than the window would otherwise run unpermuted
     const unsigned long long win = tune.xcd_window > 0 ? static_cast<unsigned long long>(tune.xcd_window) : 0;
     q.xcd_window = static_cast<uint32_t>(win < (blocks & ~7ull) ? win : (blocks & ~7ull));
-    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(O::kWG), static_cast<size_t>(tune.lds_pad > 0 ? tune.lds_pad : 0), ctx->stream, q);
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(S::WG_THREADS), static_cast<size_t>(tune.lds_pad > 0 ? tune.lds_pad : 0), ctx->stream, q);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(e, "rx_fused_kernel launch");
     return SDR_OK;
