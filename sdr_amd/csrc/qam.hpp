@@ -16,7 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #ifndef SDR_FAST_FROM
-#define SDR_FAST_FROM 3      // hard decision alone: bits per axis from which the three-point test replaces the scan
+#define SDR_FAST_FROM 2      // hard decision alone: bits per axis from which the margin slicer replaces the scan
 #endif
 
 namespace sdr {
@@ -164,6 +164,68 @@ __device__ inline unsigned nearest_fast(T ur, T ui)
     return nearest_by_scan<T, MI, MQ>(ur, ui);
 }
 
+// One axis of the margin slicer: binary level index, distance of the slicer coordinate from the
+// centre of its decision cell, and how far beyond the grid the coordinate lies (both in slicer
+// units: one unit = two grid units).
+template <typename T, int M>
+__device__ inline void axis_slice(T v, unsigned& bin, T& miss, T& beyond)
+{
+    if constexpr (M == 0) {
+        bin = 0u;
+        miss = T(0);
+        beyond = v * T(0.5);
+    } else {
+        constexpr int L = 1 << M;
+        const T t = (v + T(L - 1)) * T(0.5);
+        T tc = t > T(-0.25) ? t : T(-0.25);                       // NaN -> -0.25, and `beyond` turns NaN
+        tc = tc < T(L) - T(0.75) ? tc : T(L) - T(0.75);
+        const T a = rint(tc);                                     // 0 ... L-1
+        miss = tc - a;
+        beyond = t - tc;
+        bin = static_cast<unsigned>(static_cast<int>(a));
+    }
+}
+
+#ifndef SDR_MARGIN_OFF
+#define SDR_MARGIN_OFF 0     // 1: experiment, every hard decision takes the three-point test
+#endif
+
+// nearest() from a plain slicer whenever the point is CLEARLY inside one decision cell, about half
+// the instructions of the three-point test.  (A, B) is accepted when, on both axes, the slicer
+// coordinate t = (v + L - 1) / 2 is at most 1/2 - 2^-14 from the cell centre and at most 14 beyond
+// the outer cells (which extend outwards).  Why this is the scan's answer, float or double:
+//   * t carries an error below 2^-19 (|v + L - 1| < 128), so v is at most 1 - 2^-13 + 2^-18 from level
+//     A and at least 1 + 2^-13 - 2^-18 from every other level of that axis; beyond the grid the
+//     nearest other level is 2 further than the edge level;
+//   * the scan's rounded axis distances are monotonic in |v - level|, so every other level's
+//     differs from A's by at least that of the neighbour: more than 2^-12 inside, more than 4
+//     outside;
+//   * every squared distance is below 31^2, every sum m below 2^11 where one ulp is 2^-13: a point
+//     that differs from (A, B) on either axis has an exact sum at least 2^-12 larger and therefore
+//     a strictly larger rounded one.  m is finite, so the strict '<' scan returns (A, B).
+// Everything else -- one point in 4000 of a uniform spread, NaN, far outliers -- takes the
+// three-point test (and from there, rarely, the scan).
+template <typename T, int MI, int MQ>
+__device__ __noinline__ unsigned nearest_checked(T ur, T ui) { return nearest_fast<T, MI, MQ>(ur, ui); }
+
+template <typename T, int MI, int MQ>
+__device__ inline unsigned nearest_margin(T ur, T ui)
+{
+    if constexpr (SDR_MARGIN_OFF) return nearest_fast<T, MI, MQ>(ur, ui);
+    unsigned bi, bq;
+    T mi, mq, oi, oq;
+    axis_slice<T, MI>(ur, bi, mi, oi);
+    axis_slice<T, MQ>(ui, bq, mq, oq);
+    const T miss = fabs(mi) > fabs(mq) ? fabs(mi) : fabs(mq);
+    const bool sure = (miss <= T(0.5) - T(0.00006103515625)) && (fabs(oi) <= T(14)) && (fabs(oq) <= T(14));
+    if (sure) {
+        const unsigned w = (bi << MQ) | bq;                        // both binary indices; Gray-code them in one go
+        constexpr unsigned kKeep = MQ > 0 ? ~(1u << (MQ - 1)) : ~0u;   // I's lowest bit must not leak into Q's highest
+        return w ^ ((w >> 1) & kKeep);
+    }
+    return nearest_checked<T, MI, MQ>(ur, ui);
+}
+
 // Everything for one subcarrier: scaled coordinates -> LLRs (MI+MQ values) and index.
 template <typename T, int MI, int MQ, bool WANT_LLR, bool WANT_IDX>
 __device__ inline unsigned demap_point(T re, T im, T inorm, T w, T* llr)
@@ -172,7 +234,7 @@ __device__ inline unsigned demap_point(T re, T im, T inorm, T w, T* llr)
     const T ui = im * inorm;
     if constexpr (!WANT_LLR) {
         // hard decision alone: no need for every distance (4-level axes gain nothing from it)
-        if constexpr (WANT_IDX && (MI >= SDR_FAST_FROM || MQ >= SDR_FAST_FROM)) return nearest_fast<T, MI, MQ>(ur, ui);
+        if constexpr (WANT_IDX && (MI >= SDR_FAST_FROM || MQ >= SDR_FAST_FROM)) return nearest_margin<T, MI, MQ>(ur, ui);
     }
     T dx[1 << MI];
     T dy[1 << MQ];
@@ -185,7 +247,7 @@ __device__ inline unsigned demap_point(T re, T im, T inorm, T w, T* llr)
     unsigned idx = 0;
     if constexpr (WANT_IDX) {
         // even with every distance at hand the three-point test is cheaper than the scan from 8 levels up
-        if constexpr (MI > 2 || MQ > 2) idx = nearest_fast<T, MI, MQ>(ur, ui);
+        if constexpr (MI > 2 || MQ > 2) idx = nearest_margin<T, MI, MQ>(ur, ui);
         else idx = nearest_from_distances<T, MI, MQ>(dx, dy);
     }
     return idx;

@@ -206,7 +206,7 @@ def test_nearest_adversarial_points_bit_exact(ctx, oracle, bps, dt):
     inorm = np.sqrt(dt(2.0 * (levels * levels - 1) / 3.0)) if bps > 1 else dt(1.0)
     marks = np.arange(-(levels - 1) - 6, levels + 6, dtype=np.float64)             # levels, boundaries, beyond the edge
     # ... and the margins around the boundaries inside which the threshold decision defers to the scan
-    marks = np.concatenate([marks] + [marks + o for o in (2.0 ** -12, -2.0 ** -12, 2.0 ** -10, -2.0 ** -10)])
+    marks = np.concatenate([marks] + [marks + o for o in (2.0 ** -12, -2.0 ** -12, 2.0 ** -10, -2.0 ** -10, 2.0 ** -13, -2.0 ** -13, 28.0, -28.0, 28.5, -28.5)])
     near = []
     for v in marks:
         x = dt(v) / inorm

@@ -40,7 +40,7 @@ def main():
         bytes_sym = 8 * n + (4 * n * bps if bps else 8 * n)
         n_sym = args.symbols or max(1024, min(1 << 20, (8 << 30) // (bytes_sym + 8 * cp)))
         g = torch.Generator(device="cuda").manual_seed(1)
-        rx = torch.randn((n_sym, (n + cp) * 2), dtype=torch.float32, device="cuda", generator=g).mul_(0.05).view(torch.complex64)
+        rx = torch.randn((n_sym, (n + cp) * 2), dtype=torch.float32, device="cuda", generator=g).mul_((2.0 * n) ** -0.5).view(torch.complex64)      # bins of unit average energy, like a received constellation
         eq = wgt = None
         per = 0
         if with_eq:
