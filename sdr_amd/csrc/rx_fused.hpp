@@ -433,7 +433,13 @@ struct RxShape {
     static constexpr int TW_BYTES = O::kMidCount * 8;
     using idx_t = std::conditional_t<(BPS > 8), uint16_t, uint8_t>;      // one hard decision
     static constexpr bool HARD_PATH = (FULL || HARDONLY) && DEMAP;       // hard decisions pass through LDS and are packed
-    static constexpr int IDX_BYTES = HARD_PATH ? N * SPW * static_cast<int>(sizeof(idx_t)) : 0;
+    // Hard-only kernels park their decisions in the exchange region, dead after the transform's last
+    // exchange read (multi-wave workgroups pay one barrier for it): 10.2 -> 8.2 KiB at N = 1024.
+#ifndef SDR_HARD_IDX_ALIAS
+#define SDR_HARD_IDX_ALIAS 1
+#endif
+    static constexpr bool IDX_ALIAS = HARDONLY && SDR_HARD_IDX_ALIAS;
+    static constexpr int IDX_BYTES = (HARD_PATH && !IDX_ALIAS) ? N * SPW * static_cast<int>(sizeof(idx_t)) : 0;
     static constexpr int REF_SYM_BYTES = N * (DEMAP ? BPS : 8) / 8;      // reference bits of one symbol
     static constexpr int REF_BYTES = (FULL && DEMAP) ? REF_SYM_BYTES * SPW : 0;
     static constexpr int CHUNK = O::kGroupOut * BPS;                     // LLR floats per lane per output block
@@ -513,7 +519,10 @@ struct RxShape {
 #ifdef SDR_WPE
     static constexpr int MIN_WAVES = SDR_WPE, MAX_WAVES = SDR_WPE;
 #else
-    static constexpr int MIN_WAVES = GROUP > 1 ? 1 : LOG2N >= 13 ? ((FULL || EQ || HARDONLY) ? 1 : 2) : FULL ? SDR_EQ_WPE : EQ ? (LATE_TAPS ? 3 : SDR_EQ_WPE) : 1;
+#ifndef SDR_HARD_WPE
+#define SDR_HARD_WPE 1
+#endif
+    static constexpr int MIN_WAVES = GROUP > 1 ? 1 : (HARDONLY && LOG2N <= 10) ? SDR_HARD_WPE : LOG2N >= 13 ? ((FULL || EQ || HARDONLY) ? 1 : 2) : FULL ? SDR_EQ_WPE : EQ ? (LATE_TAPS ? 3 : SDR_EQ_WPE) : 1;
     static constexpr int even_share() { const int w = (LDS_WAVES + 3) / 4; return w < 1 ? 1 : w > 8 ? 8 : w; }
 #ifdef SDR_NO_MAX_WAVES
     static constexpr int MAX_WAVES = 8;
@@ -546,7 +555,7 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG * GROUP)
     constexpr bool LATE_TAPS = S::LATE_TAPS, LOOP = S::LOOP;
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
     unsigned char* lds_data = lds;
-    [[maybe_unused]] idx_t* lds_idx = reinterpret_cast<idx_t*>(lds + DATA_BYTES + TW_BYTES);
+    [[maybe_unused]] idx_t* lds_idx = reinterpret_cast<idx_t*>(S::IDX_ALIAS ? lds : lds + DATA_BYTES + TW_BYTES);
     [[maybe_unused]] unsigned char* lds_ref = lds + DATA_BYTES + TW_BYTES + IDX_BYTES;
 
     // GROUP > 1: `tid` is the thread's id inside its symbol's kWG threads, `gslot` the symbol's place in the workgroup
@@ -763,7 +772,7 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG * GROUP)
         }
 
         // every wave is past its last exchange read (staging strips alias it); GROUP > 1: the shared taps are in LDS
-        if constexpr (STG_ALIAS && O::kWG > 64) __syncthreads();
+        if constexpr ((STG_ALIAS || S::IDX_ALIAS) && O::kWG > 64) __syncthreads();
 
         // ---- epilogue: bins are in natural order, k = reg_pos(LAST, m) | pos_last ----
         constexpr int GO = O::kGroupOut;   // adjacent bins held in registers m = GO*h + (0..GO-1)
