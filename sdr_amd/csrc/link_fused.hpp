@@ -117,11 +117,18 @@ struct TxShape {
     static constexpr int TW_BYTES = O::kMidCount * 8;
     using idx_t = std::conditional_t<(MI + MQ > 8), uint16_t, uint8_t>;
     static constexpr int IDX_BYTES = SRC_GLOBAL ? 0 : N * SPW * static_cast<int>(sizeof(idx_t));
-    static constexpr int TIME_OFF = (DATA_BYTES + TW_BYTES + IDX_BYTES + 15) & ~15;
     // the plain batched ofdm::tx stores straight from the registers of the last pass (prefix = the
     // tail stored a second time); the generator assembles the symbol in LDS (rolled noise loops)
     static constexpr bool DIRECT = SDR_TX_DIRECT && SRC_GLOBAL && !NOISE && SPW == 1;      // several symbols per wave: the LDS-assembled rows store better (N = 64: 5.2e9 against 4.5e9 symbols/s)
-    static constexpr int LDS_BYTES = TIME_OFF + (DIRECT ? 0 : N * 8 * SPW) + 16;
+    // The assembled symbol reuses the transform's exchange region, dead after the last exchange read
+    // (one more barrier in multi-wave workgroups): 18.2 -> 10.2 KiB at N = 1024, 15 instead of 8
+    // workgroups per CU by LDS, so that the registers (three waves per SIMD) set the residency.
+#ifndef SDR_TX_TIME_ALIAS
+#define SDR_TX_TIME_ALIAS 1
+#endif
+    static constexpr bool TIME_ALIAS = SDR_TX_TIME_ALIAS && !DIRECT && N * 8 * SPW <= DATA_BYTES;
+    static constexpr int TIME_OFF = TIME_ALIAS ? 0 : (DATA_BYTES + TW_BYTES + IDX_BYTES + 15) & ~15;
+    static constexpr int LDS_BYTES = (TIME_ALIAS ? DATA_BYTES + TW_BYTES + IDX_BYTES : TIME_OFF + (DIRECT ? 0 : N * 8 * SPW)) + 16;
     // one symbol group per workgroup as straight-line code (batched ofdm::tx: +20 % at N = 4096; the
     // ALU-bound generator: +2 to +7 % over runs of two)
     static constexpr bool LOOP = !SDR_TX_STRAIGHT;
@@ -155,9 +162,9 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
     constexpr int TW_BYTES = O::kMidCount * 8;
     using idx_t = std::conditional_t<(MI + MQ > 8), uint16_t, uint8_t>;
     constexpr int IDX_BYTES = SRC_GLOBAL ? 0 : N * SPW * static_cast<int>(sizeof(idx_t));
-    constexpr int TIME_OFF = (DATA_BYTES + TW_BYTES + IDX_BYTES + 15) & ~15;
     using S = TxShape<LOG2N, MI, MQ, SRC_GLOBAL, NOISE>;
-    static_assert(S::TIME_OFF == TIME_OFF, "TxShape mirrors the kernel's LDS layout");
+    constexpr int TIME_OFF = S::TIME_OFF;
+    static_assert(S::DATA_BYTES == DATA_BYTES && S::IDX_BYTES == IDX_BYTES, "TxShape mirrors the kernel's LDS layout");
     constexpr bool DIRECT = S::DIRECT;
     __shared__ __attribute__((aligned(16))) unsigned char lds[S::LDS_BYTES];
     idx_t* lds_idx = reinterpret_cast<idx_t*>(lds + DATA_BYTES + TW_BYTES);
@@ -263,6 +270,7 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
                 });
             }
         } else {
+        if constexpr (S::TIME_ALIAS && O::kWG > 64) __syncthreads();      // every wave is past its last exchange read
         static_for<E>([&](auto M) {
             constexpr int m = M;
             lds_time[A::out_reg(m) | addr.pos_last] = make_float2(x[m].x * INV_LEN, x[m].y * INV_LEN);
@@ -354,7 +362,15 @@ struct McLds {
     using O = PlanOps<LOG2N>;
     static constexpr int DATA_BYTES = O::max_sym_bytes() * O::kSPW;
     static constexpr int TW_BYTES = O::kMidCount * 8;
-    static constexpr int TIME_BYTES = O::kN * 8 * O::kSPW;
+    // The time-domain symbol (IFFT output + noise, then the received bins for the demapping loop)
+    // lives in the transform's exchange region, which is dead whenever it is in use: 17.2 -> 9.4 KiB
+    // at N = 1024, so that registers, not LDS, bound the resident waves.
+#ifndef SDR_MC_TIME_ALIAS
+#define SDR_MC_TIME_ALIAS 1
+#endif
+    static constexpr bool TIME_ALIAS = SDR_MC_TIME_ALIAS && O::kN * 8 * O::kSPW <= DATA_BYTES;
+    static constexpr int TIME_BYTES = TIME_ALIAS ? 0 : O::kN * 8 * O::kSPW;
+    static constexpr int TIME_OFF = TIME_ALIAS ? 0 : DATA_BYTES + TW_BYTES;
     static constexpr int BYTES = DATA_BYTES + TW_BYTES + TIME_BYTES + 16;
 };
 
@@ -368,7 +384,9 @@ __device__ __forceinline__ void mc_body(const McWork& p, unsigned char* lds, con
     using A = FftAddr<LOG2N>;
     constexpr int N = O::kN, E = O::kE, TPS = O::kTPS, SPW = O::kSPW;
     constexpr int BPS = MI + MQ;
-    float2* lds_time = reinterpret_cast<float2*>(lds + McLds<LOG2N>::DATA_BYTES + McLds<LOG2N>::TW_BYTES);
+    float2* lds_time = reinterpret_cast<float2*>(lds + McLds<LOG2N>::TIME_OFF);
+    // aliased time buffer: other waves of the workgroup may still be inside the transform's last exchange
+    constexpr bool ALIAS_SYNC = McLds<LOG2N>::TIME_ALIAS && O::kWG > 64;
     const int tid = threadIdx.x;
     const int slot = tid / TPS;
     const int t = tid % TPS;
@@ -391,6 +409,7 @@ __device__ __forceinline__ void mc_body(const McWork& p, unsigned char* lds, con
         // ifft2 divides by N (fft.hpp:200-202); N is a power of two, so the product with the exact
         // reciprocal is the same correctly rounded value as the quotient, at a tenth of the cost
         constexpr float INV_LEN = 1.0f / static_cast<float>(N);
+        if constexpr (ALIAS_SYNC) __syncthreads();
         static_for<E>([&](auto M) {
             constexpr int m = M;
             const int n = A::out_reg(m) | addr.pos_last;
@@ -415,11 +434,13 @@ __device__ __forceinline__ void mc_body(const McWork& p, unsigned char* lds, con
         __syncthreads();
         // ---- receive: the CP would be dropped here (ofdm.hpp:41); its samples are never made ----
         static_for<E>([&](auto M) { constexpr int m = M; x[m] = lds_time[slot * N + (A::in_reg(m) | addr.in_thread)]; });
+        if constexpr (ALIAS_SYNC) __syncthreads();
         fft_run<LOG2N>(x, lds, addr, tw_fwd);
 
         // Demapping and counting as ROLLED loops over LDS: thread t takes Philox block j*TPS + t,
         // i.e. the eight subcarriers block + l*(N/8).  Unrolled in registers, sixteen interleaved
         // demappers (2 x 2^(bps/2) distances each) needed 500+ registers at 64/256-QAM.
+        if constexpr (ALIAS_SYNC) __syncthreads();
         static_for<E>([&](auto M) { constexpr int m = M; lds_time[slot * N + (A::out_reg(m) | addr.pos_last)] = x[m]; });
         __syncthreads();
         unsigned n_bit = 0, n_sym_err = 0, n_sign = 0;              // per symbol and thread: <= 16 points x 10 bits
