@@ -33,16 +33,22 @@ WORKLOADS = {
 }
 
 
+TRAFFIC_FILES = ("r2_traffic.json", "r1_traffic.json")      # newest first
+
+
 def measured_traffic(workload, n_sym):
-    """HBM bytes per launch from the committed PMC passes (profiles/r1_traffic.json: FETCH_SIZE and
-    WRITE_SIZE collected in separate rocprofv3 runs of this script, gfx950 correction applied);
-    None when no pass exists for the workload."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as f:
-            k = json.load(f)["kernels"].get(workload)
-        return None if k is None else k["hbm_bytes_per_symbol"] * n_sym
-    except (OSError, ValueError, KeyError):
-        return None
+    """(HBM bytes per launch, file) from the committed PMC passes (profiles/r2_traffic.json, else round
+    1's: FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 runs of this script by
+    tools/profile_bench.sh, gfx950 correction applied); (None, None) when no pass covers the workload."""
+    for name in TRAFFIC_FILES:
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                k = json.load(f)["kernels"].get(workload)
+            if k is not None:
+                return k["hbm_bytes_per_symbol"] * n_sym, name
+        except (OSError, ValueError, KeyError):
+            continue
+    return None, None
 
 
 def algorithmic_bytes_per_symbol(n_fft, bps):
@@ -152,15 +158,17 @@ def time_workload(ctx, torch, dist, name, steps, warmup, world, rank, n_sym_over
     # 8(d) leaves them out of the algorithmic count ("amortised / L2-resident"), so `frac` does too;
     # the bytes are real (2.7 % at 14 symbols per set) and are reported beside it.
     tap_bytes_sym = (12.0 * n_fft / per) if with_eq else 0.0
+    traffic, traffic_file = measured_traffic(name, n_sym)
     res = {
         "n_fft": n_fft, "cp": cp, "bps": bps, "n_sym": n_sym, "elapsed": elapsed, "with_eq": with_eq,
         "tap_bytes_per_symbol": tap_bytes_sym, "frac_incl_taps": (b_sym + tap_bytes_sym) * n_sym / avg_launch_s / 1e9 / HBM_PEAK_GBS,
         "sym_per_s": world * n_sym * steps / elapsed,
         "copy_shape_gbs": copy_gbs,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": measured_traffic(name, n_sym), "traffic_unit": "bytes per launch (rocprofv3 PMC, separate passes; profiles/r1_traffic.json)",
+                     "traffic": traffic, "traffic_unit": f"bytes per launch (rocprofv3 PMC, separate passes; profiles/{traffic_file})",
                      "algorithmic_bytes_per_launch": b_sym * n_sym, "bytes_per_symbol": b_sym, "symbols_per_launch": n_sym, "avg_launch_ms": avg_launch_s * 1e3},
     }
+    res["buffers"] = {k: hex(v.data_ptr()) for k, v in (("rx", rx), ("llr", llr), ("eq", eq), ("wgt", wgt)) if v is not None}      # placement, for the record
     del rx, llr, eq, wgt
     torch.cuda.empty_cache()
     return res
@@ -265,7 +273,7 @@ def main():
             r = time_workload(ctx, torch, dist, name, max(3, args.steps // 2), 5, 1, 0)
             extra[name] = {"sym_per_s": r["sym_per_s"], "llr_gbit_per_s": r["sym_per_s"] * r["n_fft"] * r["bps"] / 1e9,
                            "hbm_frac": r["roofline"]["frac"], "achieved_GBs": r["roofline"]["achieved"], "symbols": r["n_sym"],
-                           "equaliser": r["with_eq"]}
+                           "equaliser": r["with_eq"], "hbm_traffic_bytes_per_launch": r["roofline"]["traffic"]}
             if r["with_eq"]:
                 extra[name]["hbm_frac_incl_tap_bytes"] = r["frac_incl_taps"]
                 extra[name]["tap_bytes_per_symbol"] = r["tap_bytes_per_symbol"]
