@@ -247,7 +247,7 @@ __device__ inline unsigned demap_point(T re, T im, T inorm, T w, T* llr)
     unsigned idx = 0;
     if constexpr (WANT_IDX) {
         // even with every distance at hand the three-point test is cheaper than the scan from 8 levels up
-        if constexpr (MI > 2 || MQ > 2) idx = nearest_margin<T, MI, MQ>(ur, ui);
+        if constexpr (MI >= SDR_FAST_FROM || MQ >= SDR_FAST_FROM) idx = nearest_margin<T, MI, MQ>(ur, ui);
         else idx = nearest_from_distances<T, MI, MQ>(dx, dy);
     }
     return idx;
