@@ -27,6 +27,31 @@ if ROOT not in sys.path:
 DEFAULT_MAX_DB = {2: 10, 4: 14, 6: 18, 8: 24}
 
 
+# VALU-issue cost of ONE OFDM symbol in the fused Monte-Carlo kernel at n_fft = 1024, in SIMD cycles:
+# instruction-class counts from rocprofv3 PMC passes (profiles/r2_pmc_instruction_classes_65536sym.txt and
+# the same passes for the other modulations) weighted with the issue cost tools/valubench measured on
+# MI355X (profiles/r2_valubench_issue_cost.txt: VOP1/VOP2 2.15, packed fp32 4.1, v_mad_u64_u32 4.6,
+# transcendental 10 cycles per wave64 instruction).  Key: bits per subcarrier.
+VALU_ISSUE_CYCLES_PER_SYMBOL_1024 = {1: 11680, 2: 12827, 4: 14373, 6: 16390, 8: 19645, 10: 25891}
+VALU_LANE_INSTR_PER_SYMBOL_1024 = {1: 244638, 2: 274592, 4: 313818, 6: 369901, 8: 462832, 10: 644773}
+SIMD_CYCLES_PER_S = 256 * 4 * 2.4e9      # 256 CUs x 4 SIMDs at the 2.4 GHz peak engine clock (MI355X_MICROARCH.md)
+
+
+def valu_roofline(points, counters, n_fft, elapsed, world):
+    """The sweep kernel touches no HBM beyond its counters: its roofline is the VALU issue rate."""
+    if n_fft != 1024:
+        return None
+    cycles = lanes = 0.0
+    for p, r in zip(points, counters):
+        cycles += r[4] * VALU_ISSUE_CYCLES_PER_SYMBOL_1024[p.mod_bits]      # counter 4 = OFDM symbols of the point
+        lanes += r[4] * VALU_LANE_INSTR_PER_SYMBOL_1024[p.mod_bits]
+    achieved = cycles / elapsed
+    return {"bound": "valu", "achieved": achieved / 1e12, "peak": world * SIMD_CYCLES_PER_S / 1e12, "unit": "T SIMD issue cycles/s",
+            "frac": achieved / (world * SIMD_CYCLES_PER_S), "lane_instructions_per_s": lanes / elapsed,
+            "note": "achieved = sum over points of symbols x measured VALU issue cycles per symbol; the shader clock under this load is 1.9-2.4 GHz, so frac understates the busy share by up to 20 %",
+            "traffic": None}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--bits", type=float, default=1e10, help="total bits over the whole sweep")
@@ -123,6 +148,7 @@ def main():
             "scaling": "strong", "collective": "one all_reduce(SUM) of %d int64" % (len(points) * 8),
             "launches_per_sweep": (len(points) if args.per_point else 1),
             "checksum_bit_errors": sum(r[0] for r in c),
+            "dtype": "f32", "roofline": valu_roofline(points, c, args.n_fft, elapsed, world),
             "counters": c,
         }))
     ctx.close()
