@@ -404,6 +404,9 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 #ifndef SDR_EQ_WPE
 #define SDR_EQ_WPE 2
 #endif
+#ifndef SDR_EQ_FORCE_LOOP
+#define SDR_EQ_FORCE_LOOP 0      // 1: experiment, every tap-holding variant takes the run of two again
+#endif
 #ifndef SDR_EQ_NOLOOP
 #define SDR_EQ_NOLOOP 0
 #endif
@@ -505,7 +508,22 @@ struct RxShape {
     // beside LLRs: 63 -> 68 %; N = 8192: 56 -> 71 %).  Counting variants then end every symbol with
     // four atomics per wave on the 1024 counter slots, which measured no slower than runs of eight.
     // (The name is historical: the run of two is written out, see `process` in the kernel.)
-    static constexpr bool LOOP = EQ && !LATE_TAPS && !SDR_EQ_NOLOOP && GROUP == 1;
+    // Round 2: where it measured faster (same buffers, tools/occbench.py, profiles/r2_eq_straight_line_ab.txt)
+    // the tap-holding variant is straight-line too -- one symbol group per workgroup, taps and weights
+    // requested unconditionally BEHIND the samples, so that the wait in front of the transform covers the
+    // samples only (vmcnt counts the tap loads as still outstanding) and the taps land during it.  Twice
+    // the tap requests through L2, but three waves per SIMD instead of two and no loads queued behind a
+    // previous symbol's stores: +1 to +7 points at N = 64...256, 1024 (16-QAM up), 2048, 4096; N = 512 and
+    // QPSK at 1024 lose 0.4 to 6.7 points with it and N = 8192 is level: those keep the run of two.
+#ifdef SDR_EQ_TAPS_AFTER
+    static constexpr bool EQ_STRAIGHT_RULE = true;
+#else
+    static constexpr bool EQ_STRAIGHT_RULE = FULL ? (LOG2N == 11)      // with hard bits / counters: +2 at N = 2048, -3.6 at 1024, -1.6 at 4096
+                                                  : (LOG2N <= 8 || (LOG2N == 10 && BPS >= 4) || LOG2N == 11 || LOG2N == 12);
+#endif
+    static constexpr bool EQ_STRAIGHT = EQ && DEMAP && !LATE_TAPS && GROUP == 1 && EQ_STRAIGHT_RULE && !SDR_EQ_FORCE_LOOP;
+    static constexpr bool TAPS_AFTER = EQ_STRAIGHT;
+    static constexpr bool LOOP = EQ && !LATE_TAPS && !SDR_EQ_NOLOOP && GROUP == 1 && !EQ_STRAIGHT;
 
     // Waves per SIMD.  Lower bound = register budget: the tap-holding and FULL variants must not
     // drift to 256+ registers (one wave per SIMD); at N = 8192 (E = 32) FULL variants are held to
@@ -684,14 +702,12 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG * GROUP)
             });
             }
         };
-#ifndef SDR_EQ_TAPS_AFTER
-        if constexpr (PREFETCH_TAPS && !LATE_TAPS) {
+        if constexpr (PREFETCH_TAPS && !LATE_TAPS && !S::TAPS_AFTER) {
             if (tap_set != held_set) {
                 held_set = tap_set;
                 load_taps();
             }
         }
-#endif
 
         // Reference bits of the symbol (counting only): requested ahead of the samples, parked
         // in LDS before the transform.  Unconditional (see the taps above); a
@@ -747,14 +763,7 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG * GROUP)
             // on the GROUP symbols run independently (one-wave symbols: no further barrier at all).
             __syncthreads();
         }
-#ifdef SDR_EQ_TAPS_AFTER     // experiment: taps requested behind the samples
-        if constexpr (PREFETCH_TAPS && !LATE_TAPS) {
-            if (tap_set != held_set) {
-                held_set = tap_set;
-                load_taps();
-            }
-        }
-#endif
+        if constexpr (PREFETCH_TAPS && !LATE_TAPS && S::TAPS_AFTER) load_taps();      // straight-line: unconditional, behind the samples
         if constexpr (FULL && DEMAP) {
             static_for<REF_PER_THREAD>([&](auto R) {
                 constexpr int r = R;
