@@ -398,8 +398,14 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 #ifndef SDR_LATE_TAPS_FULL
 #define SDR_LATE_TAPS_FULL 0
 #endif
+#ifndef SDR_LATE_FROM
+#define SDR_LATE_FROM 11
+#endif
+#ifndef SDR_LATE_WPE
+#define SDR_LATE_WPE 3
+#endif
 #ifndef SDR_LATE_TAPS
-#define SDR_LATE_TAPS 0
+#define SDR_LATE_TAPS -1     // -1: per-shape rule (RxShape::LATE_TAPS), 0: never, 1: N = 2^SDR_LATE_FROM ... 4096
 #endif
 #ifndef SDR_EQ_WPE
 #define SDR_EQ_WPE 2
@@ -497,11 +503,14 @@ struct RxShape {
     static constexpr int LDS_THROTTLE = wg_per_cu_target() > 0 ? ((160 * 1024 / wg_per_cu_target()) & ~511) : 0;
     static constexpr int LDS_BYTES = LDS_USED > LDS_THROTTLE ? LDS_USED : LDS_THROTTLE;
 
-    // Alternative to holding the taps across a run of two symbols, OFF by default (measured within
-    // a point of it at N = 2048 / 4096, worse at N = 1024): requested per symbol ahead of an exchange
-    // barrier (SDR_LATE_AT: 0 = first exchange, 1 = second) -- 48 fewer live registers, three waves
-    // per SIMD instead of two, but twice the tap traffic through L2.
-    static constexpr bool LATE_TAPS = EQ && DEMAP && O::kPasses == 3 && (FULL ? SDR_LATE_TAPS_FULL : (SDR_LATE_TAPS && LOG2N >= 11 && LOG2N <= 12));
+    // Alternative to holding the taps across a run of two symbols: requested per symbol ahead of an
+    // exchange barrier (SDR_LATE_AT: 0 = first exchange, 1 = second) -- 48 fewer live registers, three
+    // waves per SIMD instead of two, but twice the tap traffic through L2.  Round 1 measured it within a
+    // point of the run of two; against round 2's straight form it wins at N = 2048 (64-QAM up) and 4096
+    // (profiles/r2_eq_straight_line_ab.txt) and is what those shapes use.  Four waves per SIMD spill (-15 points).
+    static constexpr bool LATE_TAPS = EQ && DEMAP && O::kPasses == 3 && (FULL ? SDR_LATE_TAPS_FULL
+                                              : SDR_LATE_TAPS < 0 ? ((LOG2N == 11 && BPS >= 6) || LOG2N == 12)      // same-box A/B against the straight form: +0.6 to +1.4 points (2048/16-QAM: -0.7)
+                                                                  : (SDR_LATE_TAPS && LOG2N >= SDR_LATE_FROM && LOG2N <= 12));
     // Only the tap-holding instantiations take a run of symbol groups per workgroup (taps reloaded
     // once per run).  The others take exactly one group and are straight-line code: nothing is
     // hoisted out of a loop into registers (N = 1024 LLR variant: 136 -> 104-119 registers; hard bits
@@ -540,7 +549,7 @@ struct RxShape {
 #ifndef SDR_HARD_WPE
 #define SDR_HARD_WPE 1
 #endif
-    static constexpr int MIN_WAVES = GROUP > 1 ? 1 : (HARDONLY && LOG2N <= 10) ? SDR_HARD_WPE : LOG2N >= 13 ? ((FULL || EQ || HARDONLY) ? 1 : 2) : FULL ? SDR_EQ_WPE : EQ ? (LATE_TAPS ? 3 : SDR_EQ_WPE) : 1;
+    static constexpr int MIN_WAVES = GROUP > 1 ? 1 : (HARDONLY && LOG2N <= 10) ? SDR_HARD_WPE : LOG2N >= 13 ? ((FULL || EQ || HARDONLY) ? 1 : 2) : FULL ? SDR_EQ_WPE : EQ ? (LATE_TAPS ? SDR_LATE_WPE : SDR_EQ_WPE) : 1;
     static constexpr int even_share() { const int w = (LDS_WAVES + 3) / 4; return w < 1 ? 1 : w > 8 ? 8 : w; }
 #ifdef SDR_NO_MAX_WAVES
     static constexpr int MAX_WAVES = 8;
