@@ -219,8 +219,8 @@ def time_chain(ctx, torch, name, steps, warmup, n_sym_override=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)      # 50 x 4.4 ms: a 0.2 s timed region
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="fft1024_16qam_1M", choices=sorted(WORKLOADS))
     ap.add_argument("--chain", default="", choices=[""] + sorted(CHAIN), help="only run this chunked whole-link configuration and print its JSON")
     ap.add_argument("--symbols", type=int, default=0, help="override symbols per GPU (debug)")
