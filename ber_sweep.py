@@ -34,17 +34,22 @@ DEFAULT_MAX_DB = {2: 10, 4: 14, 6: 18, 8: 24}
 # transcendental 10 cycles per wave64 instruction).  Key: bits per subcarrier.
 VALU_ISSUE_CYCLES_PER_SYMBOL_1024 = {1: 11680, 2: 12827, 4: 14373, 6: 16390, 8: 19645, 10: 25891}
 VALU_LANE_INSTR_PER_SYMBOL_1024 = {1: 244638, 2: 274592, 4: 313818, 6: 369901, 8: 462832, 10: 644773}
+# the same for the hard-only bodies (SDR_POINT_HARD_ONLY; profiles/r2_pmc_instruction_classes_mc_hard_only_65536sym.txt)
+VALU_ISSUE_CYCLES_PER_SYMBOL_1024_HARD = {1: 11413, 2: 12086, 4: 12059, 6: 12151, 8: 12241, 10: 12530}
+VALU_LANE_INSTR_PER_SYMBOL_1024_HARD = {1: 236032, 2: 252344, 4: 253783, 6: 256510, 8: 259214, 10: 267751}
 SIMD_CYCLES_PER_S = 256 * 4 * 2.4e9      # 256 CUs x 4 SIMDs at the 2.4 GHz peak engine clock (MI355X_MICROARCH.md)
 
 
-def valu_roofline(points, counters, n_fft, elapsed, world):
+def valu_roofline(points, counters, n_fft, elapsed, world, hard_only=False):
     """The sweep kernel touches no HBM beyond its counters: its roofline is the VALU issue rate."""
-    if n_fft != 1024:
+    if n_fft != 1024 or hard_only and not VALU_ISSUE_CYCLES_PER_SYMBOL_1024_HARD:
         return None
     cycles = lanes = 0.0
+    cyc_tab = VALU_ISSUE_CYCLES_PER_SYMBOL_1024_HARD if hard_only else VALU_ISSUE_CYCLES_PER_SYMBOL_1024
+    lane_tab = VALU_LANE_INSTR_PER_SYMBOL_1024_HARD if hard_only else VALU_LANE_INSTR_PER_SYMBOL_1024
     for p, r in zip(points, counters):
-        cycles += r[4] * VALU_ISSUE_CYCLES_PER_SYMBOL_1024[p.mod_bits]      # counter 4 = OFDM symbols of the point
-        lanes += r[4] * VALU_LANE_INSTR_PER_SYMBOL_1024[p.mod_bits]
+        cycles += r[4] * cyc_tab[p.mod_bits]      # counter 4 = OFDM symbols of the point
+        lanes += r[4] * lane_tab[p.mod_bits]
     achieved = cycles / elapsed
     return {"bound": "valu", "achieved": achieved / 1e12, "peak": world * SIMD_CYCLES_PER_S / 1e12, "unit": "T SIMD issue cycles/s",
             "frac": achieved / (world * SIMD_CYCLES_PER_S), "lane_instructions_per_s": lanes / elapsed,
@@ -61,6 +66,7 @@ def main():
     ap.add_argument("--step-db", type=float, default=1.0)
     ap.add_argument("--seed", type=int, default=5)
     ap.add_argument("--repeat", type=int, default=1, help="timed repetitions of the sweep")
+    ap.add_argument("--hard-only", action="store_true", help="SDR_POINT_HARD_ONLY on every point: BER from hard decisions alone (the reference's chain), no LLR statistics")
     ap.add_argument("--per-point", action="store_true", help="one sdr_link_ber_c32 launch per point (the round-1 form) instead of one sdr_link_sweep_c32 launch per sweep")
     args = ap.parse_args()
 
@@ -108,7 +114,7 @@ def main():
                 if n_sym:
                     ctx.link_ber(args.n_fft, args.cp, mod, args.seed, g0, n_sym, sigma, w, counters=counters[i])
         else:
-            ctx.link_sweep(args.n_fft, args.cp, args.seed, mine, counters)      # ONE launch for the whole sweep
+            ctx.link_sweep(args.n_fft, args.cp, args.seed, mine, counters, hard_only=args.hard_only)      # ONE launch for the whole sweep
         if world > 1:
             if dist.get_backend() == "nccl":
                 dist.all_reduce(counters, op=dist.ReduceOp.SUM)  # the only collective: O(KiB) of int64 over RCCL
@@ -148,7 +154,8 @@ def main():
             "scaling": "strong", "collective": "one all_reduce(SUM) of %d int64" % (len(points) * 8),
             "launches_per_sweep": (len(points) if args.per_point else 1),
             "checksum_bit_errors": sum(r[0] for r in c),
-            "dtype": "f32", "roofline": valu_roofline(points, c, args.n_fft, elapsed, world),
+            "dtype": "f32", "hard_only": bool(args.hard_only),
+            "roofline": valu_roofline(points, c, args.n_fft, elapsed, world, args.hard_only),
             "counters": c,
         }))
     ctx.close()

@@ -215,11 +215,16 @@ int sdr_link_ber_c32(sdr_ctx* ctx, const sdr_link_args* args);
  * point i.  Same results as one sdr_link_ber_c32 call per point.  `points` is HOST memory (copied
  * to the device by the call); points with n_sym = 0 are skipped.  Model of the loop:
  * app/QFDemoWindow.cpp:201-224 (one symbol per tick there). */
+/* SDR_POINT_HARD_ONLY: count bit and subcarrier-symbol errors from hard decisions alone, the way the
+ * reference's own receive chain works (ofdm::rx -> from_constl, lib/inc/ofdm.hpp:37-43 +
+ * modulation.hpp:96-112): no LLR is formed, counters 5 and 6 of the point are left as they were.
+ * Counters 0-4 are identical to those of the full form. */
+#define SDR_POINT_HARD_ONLY 1u
 typedef struct sdr_sweep_point {
     uint32_t mod;               /* sdr_modulation */
     float sigma;                /* per-component noise standard deviation, time domain */
     float llr_weight0;
-    uint32_t reserved;
+    uint32_t flags;             /* 0, or SDR_POINT_HARD_ONLY */
     uint64_t first_symbol;      /* global index of the first symbol of this point handled here */
     uint64_t n_sym;
 } sdr_sweep_point;

@@ -69,12 +69,15 @@ class LinkArgs(Structure):
     ]
 
 
+POINT_HARD_ONLY = 1     # sdr_sweep_point.flags: hard decisions only, counters 5 and 6 untouched
+
+
 class SweepPoint(Structure):
     _fields_ = [
         ("mod", c_uint32),
         ("sigma", c_float),
         ("llr_weight0", c_float),
-        ("reserved", c_uint32),
+        ("flags", c_uint32),
         ("first_symbol", c_uint64),
         ("n_sym", c_uint64),
     ]

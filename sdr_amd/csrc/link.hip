@@ -308,6 +308,7 @@ int link_sweep(sdr_ctx* ctx, const sdr_sweep_args& a)
         const sdr_sweep_point& pt = a.points[i];
         if (!valid_mod(static_cast<int>(pt.mod))) return fail(SDR_ERR_INVALID, "point %u: unknown modulation %u", i, pt.mod);
         if ((size_t(a.n_fft) * pt.mod) % 8 != 0) return fail(SDR_ERR_UNSUPPORTED, "point %u: n_fft*mod must be a multiple of 8 bits", i);
+        if (pt.flags & ~static_cast<uint32_t>(SDR_POINT_HARD_ONLY)) return fail(SDR_ERR_INVALID, "point %u: unknown flags 0x%x", i, pt.flags);
         fused = fused && rx_fused_supported(a.n_fft, pt.mod);
     }
     if (!fused) {
@@ -319,6 +320,16 @@ int link_sweep(sdr_ctx* ctx, const sdr_sweep_args& a)
             l.n_fft = a.n_fft; l.cp = a.cp; l.mod = pt.mod; l.seed = a.seed;
             l.first_symbol = pt.first_symbol; l.n_sym = pt.n_sym; l.sigma = pt.sigma; l.llr_weight0 = pt.llr_weight0;
             l.d_counters = a.d_counters + size_t(i) * 8;
+            if (pt.flags & SDR_POINT_HARD_ONLY) {
+                // the generic engine always forms LLRs: keep what counters 5 and 6 held before the call
+                // (one small device-to-device round trip through the staging arena; this is not the fast path)
+                void* keep = nullptr;
+                SDR_TRY(get_staging(ctx, 9, 16, &keep));
+                SDR_HIP(hipMemcpyAsync(keep, l.d_counters + 5, 16, hipMemcpyDeviceToDevice, ctx->stream));
+                SDR_TRY(link_ber(ctx, l));
+                SDR_HIP(hipMemcpyAsync(l.d_counters + 5, keep, 16, hipMemcpyDeviceToDevice, ctx->stream));
+                continue;
+            }
             SDR_TRY(link_ber(ctx, l));
         }
         return SDR_OK;
@@ -340,6 +351,12 @@ int link_sweep(sdr_ctx* ctx, const sdr_sweep_args& a)
     static const long knob = [] { const char* v = getenv("SDR_SWEEP_BLOCKS_PER_SLOT"); return v ? atol(v) : 0L; }();
     const unsigned long long target = static_cast<unsigned long long>(ctx->num_cu) * 8ull * static_cast<unsigned long long>(knob > 0 ? knob : 16);
     unsigned long long gpb = (total_groups + target - 1) / target;
+    // ... but a workgroup's set-up (addresses, twiddles, six atomics at the end) wants at least ~16 Ki
+    // points of work behind it, as long as every resident slot still gets a workgroup
+    const unsigned long long min_gpb = (16384ull + static_cast<unsigned long long>(a.n_fft) * spw - 1) / (static_cast<unsigned long long>(a.n_fft) * spw);
+    const unsigned long long slots = static_cast<unsigned long long>(ctx->num_cu) * 8ull;
+    const unsigned long long fill_gpb = total_groups / slots;      // largest run that still fills the slots
+    if (gpb < min_gpb) gpb = min_gpb < fill_gpb ? min_gpb : (fill_gpb > gpb ? fill_gpb : gpb);
     if (gpb < 1) gpb = 1;
     if (gpb > 0xFFFFFFFFull) gpb = 0xFFFFFFFFull;
     std::vector<SweepPointDev> table(order.size());
@@ -359,7 +376,7 @@ int link_sweep(sdr_ctx* ctx, const sdr_sweep_args& a)
         d.mod = pt.mod;
         d.row = order[j];
         d.groups_per_block = static_cast<uint32_t>(gpb);
-        d.reserved = 0;
+        d.flags = pt.flags;
         blocks += (d.n_groups + gpb - 1) / gpb;
     }
     const void* twf = nullptr;

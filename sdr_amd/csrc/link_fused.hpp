@@ -377,7 +377,9 @@ struct McLds {
 // generate -> IFFT -> + noise -> FFT -> demap -> count for the symbol groups [grp_begin, grp_end) of
 // one point.  The modulation is a template parameter; set-up that does not depend on it (addresses,
 // twiddles) is the caller's, so that one kernel can switch between several bodies.
-template <int LOG2N, int MI, int MQ>
+// HARD: hard decisions only (the reference's own receive chain ofdm::rx -> from_constl): bit and
+// symbol errors are counted, no LLR is formed and counters 5 and 6 stay untouched.
+template <int LOG2N, int MI, int MQ, bool HARD = false>
 __device__ __forceinline__ void mc_body(const McWork& p, unsigned char* lds, const FftAddr<LOG2N>& addr, const FftTwiddles<LOG2N>& tw_fwd)
 {
     using O = PlanOps<LOG2N>;
@@ -455,10 +457,11 @@ __device__ __forceinline__ void mc_body(const McWork& p, unsigned char* lds, con
                 const uint32_t ref = ((word >> (16u * (lane & 1u))) & 0xFFFFu) & ((1u << BPS) - 1u);
                 const float2 y = lds_time[slot * N + block + lane * (N / 8)];
                 float l[BPS];
-                const unsigned idx = demap_point<float, MI, MQ, true, true>(y.x, y.y, p.inorm, p.w0, l);
+                const unsigned idx = demap_point<float, MI, MQ, !HARD, true>(y.x, y.y, p.inorm, p.w0, l);
                 const unsigned diff = ref ^ idx;
                 n_bit += __popc(diff);
                 n_sym_err += (diff != 0);
+                if constexpr (HARD) continue;
                 unsigned two = 0;
                 static_for<BPS>([&](auto B) {
                     constexpr int b = B;
@@ -484,8 +487,10 @@ __device__ __forceinline__ void mc_body(const McWork& p, unsigned char* lds, con
         atomicAdd(&p.counters[1], c_n * BPS);
         atomicAdd(&p.counters[2], c_sym);
         atomicAdd(&p.counters[3], c_n);
-        atomicAdd(&p.counters[5], c_abs);
-        atomicAdd(&p.counters[6], c_sign);
+        if constexpr (!HARD) {
+            atomicAdd(&p.counters[5], c_abs);
+            atomicAdd(&p.counters[6], c_sign);
+        }
     }
     if (p.count_ofdm && tid == 0) atomicAdd(&p.counters[4], p.n_sym);
 }
@@ -531,7 +536,7 @@ struct SweepPointDev {
     uint32_t mod;
     uint32_t row;                  // row of the caller's counter array
     uint32_t groups_per_block;
-    uint32_t reserved;
+    uint32_t flags;                // sdr_sweep_point.flags (SDR_POINT_HARD_ONLY)
 };
 static_assert(sizeof(SweepPointDev) == 64, "one point per 64 bytes");
 
@@ -565,6 +570,18 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) SDR_MC_ATTR sweep_fused_k
     w.sigma = pt.sigma; w.w0 = pt.w0; w.norm = pt.norm; w.inorm = pt.inorm;
     w.count_ofdm = local == 0;
     if (w.grp_begin >= w.grp_end) return;          // uniform; the host never makes such a block
+    if (pt.flags & 1u) {                           // SDR_POINT_HARD_ONLY
+        switch (pt.mod) {
+            case 1: mc_body<LOG2N, 1, 0, true>(w, lds, addr, tw_fwd); break;
+            case 2: mc_body<LOG2N, 1, 1, true>(w, lds, addr, tw_fwd); break;
+            case 4: mc_body<LOG2N, 2, 2, true>(w, lds, addr, tw_fwd); break;
+            case 6: mc_body<LOG2N, 3, 3, true>(w, lds, addr, tw_fwd); break;
+            case 8: mc_body<LOG2N, 4, 4, true>(w, lds, addr, tw_fwd); break;
+            case 10: mc_body<LOG2N, 5, 5, true>(w, lds, addr, tw_fwd); break;
+            default: break;
+        }
+        return;
+    }
     switch (pt.mod) {
         case 1: mc_body<LOG2N, 1, 0>(w, lds, addr, tw_fwd); break;
         case 2: mc_body<LOG2N, 1, 1>(w, lds, addr, tw_fwd); break;

@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 from . import capi
-from .capi import ChainArgs, DemodArgs, LinkArgs, SweepArgs, SweepPoint, check
+from .capi import POINT_HARD_ONLY, ChainArgs, DemodArgs, LinkArgs, SweepArgs, SweepPoint, check
 
 MODS = {"bpsk": 1, "qpsk": 2, "16qam": 4, "64qam": 6, "256qam": 8, "1024qam": 10}
 
@@ -268,18 +268,22 @@ class Context:
         check(self.lib.sdr_link_ber_c32(self._h, ctypes.byref(a)))
         return counters
 
-    def link_sweep(self, n_fft: int, cp: int, seed: int, points, counters: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def link_sweep(self, n_fft: int, cp: int, seed: int, points, counters: Optional[torch.Tensor] = None, hard_only: bool = False) -> torch.Tensor:
         """sdr_link_sweep_c32: every (modulation, noise level) point of a sweep in ONE launch.
-        points = sequence of (mod, sigma, llr_weight0, first_symbol, n_sym); counters = int64
-        tensor (n_points, 8) on the device, accumulated into (created zeroed when None)."""
+        points = sequence of (mod, sigma, llr_weight0, first_symbol, n_sym[, flags]); counters = int64
+        tensor (n_points, 8) on the device, accumulated into (created zeroed when None).
+        hard_only: SDR_POINT_HARD_ONLY on every point (bit / symbol errors from hard decisions, no LLRs:
+        counters 5 and 6 are left alone)."""
         n = len(points)
         if counters is None:
             counters = torch.zeros((n, 8), dtype=torch.int64, device=self.torch_device)
         _need(counters, torch.int64, "counters", n * 8)
         table = (SweepPoint * max(n, 1))()
-        for i, (mod, sigma, w0, first, count) in enumerate(points):
+        for i, pt in enumerate(points):
+            mod, sigma, w0, first, count = pt[:5]
             table[i].mod, table[i].sigma, table[i].llr_weight0 = mod_bits(mod), float(sigma), float(w0)
             table[i].first_symbol, table[i].n_sym = int(first), int(count)
+            table[i].flags = (int(pt[5]) if len(pt) > 5 else 0) | (POINT_HARD_ONLY if hard_only else 0)
         a = SweepArgs()
         a.struct_size = ctypes.sizeof(SweepArgs)
         a.n_fft, a.cp, a.n_points, a.seed = n_fft, cp, n, seed

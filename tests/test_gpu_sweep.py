@@ -42,6 +42,40 @@ def test_sweep_one_launch_equals_per_point_calls(ctx, oracle, n, cp):
         assert got[i][1] == n_sym * n * m and got[i][4] == n_sym and got[i][0] > 0
 
 
+@pytest.mark.parametrize("n,cp", [(64, 16), (256, 64), (1024, 256), (2048, 512), (32, 8)])
+def test_sweep_hard_only_points(ctx, oracle, n, cp):
+    """SDR_POINT_HARD_ONLY (the reference's own chain: ofdm::rx -> from_constl, no LLRs): counters 0-4
+    equal the full form's and the oracle's, counters 5 and 6 are left exactly as they were; flagged and
+    unflagged points mix in one launch.  n = 32 takes the generic engine."""
+    from sdr_amd.link import noise_sigma, llr_weight
+    from sdr_amd.capi import POINT_HARD_ONLY
+    rng = np.random.default_rng(100 + n)
+    mods = [1, 2, 4, 6, 8, 10, 6, 4]
+    points, g0 = [], 3
+    for i, m in enumerate(mods):
+        db = {1: 3.0, 2: 4.0, 4: 8.0, 6: 13.0, 8: 18.0, 10: 23.0}[m] + float(rng.integers(0, 3))
+        n_sym = int(rng.integers(1, 30 if n >= 1024 else 150))
+        points.append((m, noise_sigma(n, m, db), llr_weight(m, db), g0, n_sym))
+        g0 += n_sym
+    full = ctx.link_sweep(n, cp, 77, points).cpu().numpy()
+    start = torch.zeros((len(points), 8), dtype=torch.int64, device="cuda")
+    start[:, 5], start[:, 6] = 1234, 99                      # must survive a hard-only point
+    hard = ctx.link_sweep(n, cp, 77, points, start.clone(), hard_only=True).cpu().numpy()
+    mixed_pts = [pt + ((POINT_HARD_ONLY if i % 2 else 0),) for i, pt in enumerate(points)]
+    mixed = ctx.link_sweep(n, cp, 77, mixed_pts).cpu().numpy()
+    for i, (m, sigma, w, first, n_sym) in enumerate(points):
+        want = oracle.link_ber(n, cp, m, 77, first, n_sym, np.float32(sigma), np.float32(w))
+        assert np.array_equal(full[i].astype(np.uint64), want), (i, m)
+        assert np.array_equal(hard[i][:5], full[i][:5]), (i, m)
+        assert hard[i][5] == 1234 and hard[i][6] == 99 and hard[i][7] == 0
+        if i % 2:
+            assert np.array_equal(mixed[i][:5], full[i][:5]) and mixed[i][5] == 0 and mixed[i][6] == 0
+        else:
+            assert np.array_equal(mixed[i], full[i])
+    with pytest.raises(RuntimeError):
+        ctx.link_sweep(n, cp, 77, [points[0] + (2,)])       # unknown flag bit
+
+
 def test_sweep_argument_errors(ctx):
     from sdr_amd.capi import SdrError, SDR_ERR_INVALID, SDR_ERR_NOT_POW2
     with pytest.raises(SdrError) as e:

@@ -59,7 +59,7 @@ def main():
         no_llr = "nollr" in parts[2:]
         if no_llr:
             bytes_sym -= 4 * n * bps
-        if "gen" in parts[2:] or "mc" in parts[2:]:
+        if "gen" in parts[2:] or "mc" in parts[2:] or "mch" in parts[2:]:
             # frame generator with noise (bytes = samples written) / Monte-Carlo link (no HBM traffic: reported as LLR-equivalent bytes)
             del rx
             rx = None
@@ -72,7 +72,10 @@ def main():
                 n_sym = args.symbols or (1 << 18)
                 mcnt = torch.zeros(8, dtype=torch.int64, device="cuda")
                 bytes_sym = 8 * n + 4 * n * bps
-                step = lambda: ctx.link_ber(n, cp, bps, 1, 0, n_sym, 0.01, 1.0, counters=mcnt)
+                if "mch" in parts[2:]:      # hard-only Monte-Carlo body, through the sweep entry point
+                    step = lambda: ctx.link_sweep(n, cp, 1, [(bps, 0.01, 1.0, 0, n_sym)], mcnt.view(1, 8), hard_only=True)
+                else:
+                    step = lambda: ctx.link_ber(n, cp, bps, 1, 0, n_sym, 0.01, 1.0, counters=mcnt)
         elif bps:
             out = None if no_llr else torch.empty((n_sym, n, bps), dtype=torch.float32, device="cuda")
             step = lambda: ctx.demod(rx, n, cp, bps, eq=eq, llr_weight=(wgt if wgt is not None else 1.5), sym_per_set=per, out_llr=out, want_llr=not no_llr,
