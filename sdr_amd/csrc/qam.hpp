@@ -89,19 +89,49 @@ __device__ inline unsigned nearest_from_distances(const T (&dx)[1 << MI], const 
 
 // Max-log LLRs of one axis: for axis bit b (MSB first), min over levels with Gray bit 1 minus
 // min over levels with Gray bit 0, times w.  out[0..M).
+// d is indexed by the Gray code g, so "bit b of g is 1" is every second aligned block of 2^b entries:
+// the minima of aligned blocks are shared between the bits (level s works on the block minima of
+// size 2^s and hands the pairwise minima on to level s + 1): 82 instead of 150 min operations for
+// 32 levels, 36 instead of 56 for 16.  min is exact and its NaN rule (the other operand) does not
+// depend on the grouping, so the values are those of the plain double loop.
+template <typename T, int M, int S>
+__device__ inline void axis_llr_level(const T (&cur)[1 << (M - S)], T w, T* out)
+{
+    constexpr int CNT = 1 << (M - S);
+    T d0 = cur[0], d1 = cur[1];
+#pragma unroll
+    for (int j = 2; j < CNT; j += 2) {
+        d0 = min_of<T>(d0, cur[j]);
+        d1 = min_of<T>(d1, cur[j + 1]);
+    }
+    out[M - 1 - S] = (d1 - d0) * w;
+    if constexpr (S + 1 < M) {
+        T next[CNT / 2];
+#pragma unroll
+        for (int j = 0; j < CNT / 2; ++j) next[j] = min_of<T>(cur[2 * j], cur[2 * j + 1]);
+        axis_llr_level<T, M, S + 1>(next, w, out);
+    }
+}
+
 template <typename T, int M>
 __device__ inline void axis_llr(const T (&d)[1 << M], T w, T* out)
 {
+    if constexpr (M >= 5) {
+        // 32 levels: 4979 instead of 5396 VALU instructions per wave and symbol at N = 1024; below
+        // that the plain loops fold into three-input minima and are level (16) or shorter (8)
+        axis_llr_level<T, M, 0>(d, w, out);
+    } else {
 #pragma unroll
-    for (int b = M - 1; b >= 0; --b) {
-        T d0 = T(0), d1 = T(0);
-        bool h0 = false, h1 = false;
+        for (int b = M - 1; b >= 0; --b) {
+            T d0 = T(0), d1 = T(0);
+            bool h0 = false, h1 = false;
 #pragma unroll
-        for (unsigned g = 0; g < (1u << M); ++g) {
-            if ((g >> b) & 1u) { d1 = h1 ? min_of<T>(d1, d[g]) : d[g]; h1 = true; }
-            else               { d0 = h0 ? min_of<T>(d0, d[g]) : d[g]; h0 = true; }
+            for (unsigned g = 0; g < (1u << M); ++g) {
+                if ((g >> b) & 1u) { d1 = h1 ? min_of<T>(d1, d[g]) : d[g]; h1 = true; }
+                else               { d0 = h0 ? min_of<T>(d0, d[g]) : d[g]; h0 = true; }
+            }
+            out[M - 1 - b] = (d1 - d0) * w;
         }
-        out[M - 1 - b] = (d1 - d0) * w;
     }
 }
 
