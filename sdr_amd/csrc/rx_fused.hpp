@@ -370,7 +370,7 @@ constexpr int stage_stride_bytes(int c) { return c == 6 ? 24 : c == 8 ? 48 : c =
 #ifdef SDR_NO_STAGE8
 constexpr bool stage_wanted(int c) { return c == 6 || c == 12 || c == 16; }
 #else
-constexpr bool stage_wanted(int c) { return c == 6 || c == 8 || c == 12 || c == 16 || c == 20; }
+constexpr bool stage_wanted(int c) { return c == 6 || c == 8 || c == 10 || c == 12 || c == 16 || c == 20; }
 #endif
 
 __device__ __forceinline__ unsigned ref_bits(const uint8_t* __restrict__ s, size_t pos, int nbits)
