@@ -489,7 +489,7 @@ struct RxShape {
 #ifdef SDR_NO_WG_TARGET
         return 0;
 #else
-        if (FULL || EQ || HARDONLY || !DEMAP) return 0;
+        if (FULL || EQ || HARDONLY || !DEMAP || BPS == 1) return 0;      // BPSK (2:1 read-dominated) was not part of the sweep
         switch (LOG2N) {
             case 6: return BPS <= 8 ? (BPS == 4 ? 9 : 8) : 0;
             case 7: return BPS <= 4 ? 6 : BPS == 6 ? 7 : BPS == 8 ? 8 : 0;

@@ -39,7 +39,8 @@ int SDR_CAT(rx_fused_dispatch_, SDR_LOG2N)(sdr_ctx* ctx, const RxParams& p, int 
     }
     switch (mod) {
         case 0: return launch_rx_fused<L, 0, 0, true, false>(ctx, p);
-        case 1:                                                       // BPSK: full variants only
+        case 1:                                                       // BPSK: LLR-only without taps, or the full variants
+            if (variant == 0) return launch_rx_fused<L, 1, 0, false, false>(ctx, p);
             return (variant & 1) ? launch_rx_fused<L, 1, 0, true, true>(ctx, p) : launch_rx_fused<L, 1, 0, true, false>(ctx, p);
         case 2: SDR_RX_CASE(1, 1)
         case 4: SDR_RX_CASE(2, 2)
