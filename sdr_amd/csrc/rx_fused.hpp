@@ -398,6 +398,12 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 #ifndef SDR_LATE_TAPS_FULL
 #define SDR_LATE_TAPS_FULL 0
 #endif
+#ifndef SDR_LATE_13
+#define SDR_LATE_13 0
+#endif
+#ifndef SDR_LATE_13_WPE
+#define SDR_LATE_13_WPE 2
+#endif
 #ifndef SDR_LATE_FROM
 #define SDR_LATE_FROM 11
 #endif
@@ -509,7 +515,7 @@ struct RxShape {
     // point of the run of two; against round 2's straight form it wins at N = 2048 (64-QAM up) and 4096
     // (profiles/r2_eq_straight_line_ab.txt) and is what those shapes use.  Four waves per SIMD spill (-15 points).
     static constexpr bool LATE_TAPS = EQ && DEMAP && O::kPasses == 3 && (FULL ? SDR_LATE_TAPS_FULL
-                                              : SDR_LATE_TAPS < 0 ? ((LOG2N == 11 && BPS >= 6) || LOG2N == 12)      // same-box A/B against the straight form: +0.6 to +1.4 points (2048/16-QAM: -0.7)
+                                              : SDR_LATE_TAPS < 0 ? ((LOG2N == 11 && BPS >= 6) || LOG2N == 12 || (SDR_LATE_13 && LOG2N == 13))      // same-box A/B against the straight form: +0.6 to +1.4 points (2048/16-QAM: -0.7)
                                                                   : (SDR_LATE_TAPS && LOG2N >= SDR_LATE_FROM && LOG2N <= 12));
     // Only the tap-holding instantiations take a run of symbol groups per workgroup (taps reloaded
     // once per run).  The others take exactly one group and are straight-line code: nothing is
@@ -530,9 +536,16 @@ struct RxShape {
     static constexpr bool EQ_STRAIGHT_RULE = FULL ? (LOG2N == 11)      // with hard bits / counters: +2 at N = 2048, -3.6 at 1024, -1.6 at 4096
                                                   : (LOG2N <= 8 || (LOG2N == 10 && BPS >= 4) || LOG2N == 11 || LOG2N == 12);
 #endif
+    // N = 8192 (E = 32): 96 tap registers beside 64 of data and the last pass's twiddles do not fit 256
+    // (one wave per SIMD, or spills with late taps); there the epilogue reads each register group's taps
+    // and weights right where it uses them and leaves the hoisting to the compiler.
+#ifndef SDR_EPILOGUE_TAPS_13
+#define SDR_EPILOGUE_TAPS_13 1      // same-box A/B: +0.2 to +9.5 points over one wave per SIMD with held taps (profiles/r2_eq_straight_line_ab.txt)
+#endif
+    static constexpr bool EPILOGUE_TAPS = EQ && DEMAP && !FULL && GROUP == 1 && LOG2N == 13 && SDR_EPILOGUE_TAPS_13;
     static constexpr bool EQ_STRAIGHT = EQ && DEMAP && !LATE_TAPS && GROUP == 1 && EQ_STRAIGHT_RULE && !SDR_EQ_FORCE_LOOP;
     static constexpr bool TAPS_AFTER = EQ_STRAIGHT;
-    static constexpr bool LOOP = EQ && !LATE_TAPS && !SDR_EQ_NOLOOP && GROUP == 1 && !EQ_STRAIGHT;
+    static constexpr bool LOOP = EQ && !LATE_TAPS && !SDR_EQ_NOLOOP && GROUP == 1 && !EQ_STRAIGHT && !EPILOGUE_TAPS;
 
     // Waves per SIMD.  Lower bound = register budget: the tap-holding and FULL variants must not
     // drift to 256+ registers (one wave per SIMD); at N = 8192 (E = 32) FULL variants are held to
@@ -549,7 +562,7 @@ struct RxShape {
 #ifndef SDR_HARD_WPE
 #define SDR_HARD_WPE 1
 #endif
-    static constexpr int MIN_WAVES = GROUP > 1 ? 1 : (HARDONLY && LOG2N <= 10) ? SDR_HARD_WPE : LOG2N >= 13 ? ((FULL || EQ || HARDONLY) ? 1 : 2) : FULL ? SDR_EQ_WPE : EQ ? (LATE_TAPS ? SDR_LATE_WPE : SDR_EQ_WPE) : 1;
+    static constexpr int MIN_WAVES = GROUP > 1 ? 1 : (HARDONLY && LOG2N <= 10) ? SDR_HARD_WPE : LOG2N >= 13 ? (LATE_TAPS ? SDR_LATE_13_WPE : EPILOGUE_TAPS ? 2 : (FULL || EQ || HARDONLY) ? 1 : 2) : FULL ? SDR_EQ_WPE : EQ ? (LATE_TAPS ? SDR_LATE_WPE : SDR_EQ_WPE) : 1;
     static constexpr int even_share() { const int w = (LDS_WAVES + 3) / 4; return w < 1 ? 1 : w > 8 ? 8 : w; }
 #ifdef SDR_NO_MAX_WAVES
     static constexpr int MAX_WAVES = 8;
@@ -650,7 +663,7 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG * GROUP)
     const unsigned long long grp_begin = wg * p.groups_per_wg;
     const unsigned long long grp_end = (grp_begin + p.groups_per_wg < n_groups) ? grp_begin + p.groups_per_wg : n_groups;
     float2 x[E];
-    constexpr bool PREFETCH_TAPS = EQ && DEMAP && GROUP == 1;
+    constexpr bool PREFETCH_TAPS = EQ && DEMAP && GROUP == 1 && !S::EPILOGUE_TAPS;
     [[maybe_unused]] float2 eqv[PREFETCH_TAPS ? E : 1];
     [[maybe_unused]] float wv[PREFETCH_TAPS ? E : 1];
     [[maybe_unused]] size_t held_set = ~static_cast<size_t>(0);     // set whose taps the registers hold
@@ -814,6 +827,20 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG * GROUP)
                 const int k = O::reg_pos(LAST, h * GO) | pos_last;
                 float l[GO * BPS];
                 unsigned idx[GO];
+                // EPILOGUE_TAPS: this register group's taps and weights, read unconditionally (dummy source when an
+                // array is missing) so that the compiler can count and hoist the loads
+                [[maybe_unused]] float2 epi_eq[GO];
+                [[maybe_unused]] float epi_w[GO];
+                if constexpr (S::EPILOGUE_TAPS) {
+                    const float2* dummy = p.rx + static_cast<size_t>(sym) * in_stride;
+                    const float2* eq_src = p.eq ? p.eq + tap_set * N : dummy;
+                    const float* wgt_src = p.wgt ? p.wgt + tap_set * N : reinterpret_cast<const float*>(dummy);
+                    static_assert(GO == 2, "pairs of adjacent bins");
+                    const float4 v = *reinterpret_cast<const float4*>(eq_src + k);
+                    const float2 u = *reinterpret_cast<const float2*>(wgt_src + k);
+                    epi_eq[0] = make_float2(v.x, v.y); epi_eq[1] = make_float2(v.z, v.w);
+                    epi_w[0] = u.x; epi_w[1] = u.y;
+                }
                 static_for<GO>([&](auto G) {
                     constexpr int g = G;
                     float2 y = x[h * GO + g];
@@ -823,6 +850,7 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG * GROUP)
                             float2 gk;
                             if constexpr (PREFETCH_TAPS) gk = eqv[h * GO + g];
                             else if constexpr (GROUP > 1) gk = reinterpret_cast<const float2*>(lds + S::TAPS_OFF)[k + g];
+                            else if constexpr (S::EPILOGUE_TAPS) gk = epi_eq[g];
                             else gk = p.eq[tap_set * N + k + g];
                             const float er = y.x * gk.x - y.y * gk.y;
                             const float ei = y.x * gk.y + y.y * gk.x;
@@ -831,6 +859,7 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG * GROUP)
                         if (p.wgt) {
                             if constexpr (PREFETCH_TAPS) w = wv[h * GO + g];
                             else if constexpr (GROUP > 1) w = reinterpret_cast<const float*>(lds + S::TAPS_OFF + 8 * N)[k + g];
+                            else if constexpr (S::EPILOGUE_TAPS) w = epi_w[g];
                             else w = p.wgt[tap_set * N + k + g];
                         }
                     }
