@@ -398,6 +398,9 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 #ifndef SDR_LATE_TAPS_FULL
 #define SDR_LATE_TAPS_FULL 0
 #endif
+#ifndef SDR_EQ_FORM_12_10
+#define SDR_EQ_FORM_12_10 1
+#endif
 #ifndef SDR_LATE_13
 #define SDR_LATE_13 0
 #endif
@@ -509,13 +512,32 @@ struct RxShape {
     static constexpr int LDS_THROTTLE = wg_per_cu_target() > 0 ? ((160 * 1024 / wg_per_cu_target()) & ~511) : 0;
     static constexpr int LDS_BYTES = LDS_USED > LDS_THROTTLE ? LDS_USED : LDS_THROTTLE;
 
+    // How the LLR-only tap-holding variant gets its taps, per shape, from same-buffer A/Bs of two builds inside
+    // one process (tools/abbench.py, profiles/r2_eq_straight_line_ab.txt):
+    //   0  run of two symbols, taps held in registers and requested ahead of the samples when the set changes
+    //   1  straight-line, one symbol group per workgroup, taps requested unconditionally behind the samples
+    //   2  straight-line, taps requested per symbol ahead of the first exchange barrier (LATE_TAPS)
+    //   3  straight-line, taps read in the epilogue where they are used (EPILOGUE_TAPS; N = 8192)
+    static constexpr int eq_form()
+    {
+        switch (LOG2N) {
+            case 6: return BPS == 2 ? 0 : 1;
+            case 7: return 1;
+            case 8: return BPS <= 4 ? 0 : 1;
+            case 10: return (BPS == 2 || BPS == 10) ? 0 : 1;
+            case 11: return (BPS == 2 || BPS == 10) ? 0 : BPS == 4 ? 1 : 2;
+            case 12: return BPS <= 4 ? 0 : BPS == 10 ? SDR_EQ_FORM_12_10 : 2;
+            case 13: return 3;
+            default: return 0;      // N = 512: the run of two
+        }
+    }
     // Alternative to holding the taps across a run of two symbols: requested per symbol ahead of an
     // exchange barrier (SDR_LATE_AT: 0 = first exchange, 1 = second) -- 48 fewer live registers, three
     // waves per SIMD instead of two, but twice the tap traffic through L2.  Round 1 measured it within a
     // point of the run of two; against round 2's straight form it wins at N = 2048 (64-QAM up) and 4096
     // (profiles/r2_eq_straight_line_ab.txt) and is what those shapes use.  Four waves per SIMD spill (-15 points).
     static constexpr bool LATE_TAPS = EQ && DEMAP && O::kPasses == 3 && (FULL ? SDR_LATE_TAPS_FULL
-                                              : SDR_LATE_TAPS < 0 ? ((LOG2N == 11 && BPS >= 6) || LOG2N == 12 || (SDR_LATE_13 && LOG2N == 13))      // same-box A/B against the straight form: +0.6 to +1.4 points (2048/16-QAM: -0.7)
+                                              : SDR_LATE_TAPS < 0 ? (eq_form() == 2 || (SDR_LATE_13 && LOG2N == 13))      // same-box A/B against the straight form: +0.6 to +1.4 points (2048/16-QAM: -0.7)
                                                                   : (SDR_LATE_TAPS && LOG2N >= SDR_LATE_FROM && LOG2N <= 12));
     // Only the tap-holding instantiations take a run of symbol groups per workgroup (taps reloaded
     // once per run).  The others take exactly one group and are straight-line code: nothing is
@@ -534,7 +556,7 @@ struct RxShape {
     static constexpr bool EQ_STRAIGHT_RULE = true;
 #else
     static constexpr bool EQ_STRAIGHT_RULE = FULL ? (LOG2N == 11)      // with hard bits / counters: +2 at N = 2048, -3.6 at 1024, -1.6 at 4096
-                                                  : (LOG2N <= 8 || (LOG2N == 10 && BPS >= 4) || LOG2N == 11 || LOG2N == 12);
+                                                  : (eq_form() == 1);
 #endif
     // N = 8192 (E = 32): 96 tap registers beside 64 of data and the last pass's twiddles do not fit 256
     // (one wave per SIMD, or spills with late taps); there the epilogue reads each register group's taps
@@ -542,7 +564,7 @@ struct RxShape {
 #ifndef SDR_EPILOGUE_TAPS_13
 #define SDR_EPILOGUE_TAPS_13 1      // same-box A/B: +0.2 to +9.5 points over one wave per SIMD with held taps (profiles/r2_eq_straight_line_ab.txt)
 #endif
-    static constexpr bool EPILOGUE_TAPS = EQ && DEMAP && !FULL && GROUP == 1 && LOG2N == 13 && SDR_EPILOGUE_TAPS_13;
+    static constexpr bool EPILOGUE_TAPS = EQ && DEMAP && !FULL && GROUP == 1 && eq_form() == 3 && SDR_EPILOGUE_TAPS_13;
     static constexpr bool EQ_STRAIGHT = EQ && DEMAP && !LATE_TAPS && GROUP == 1 && EQ_STRAIGHT_RULE && !SDR_EQ_FORCE_LOOP;
     static constexpr bool TAPS_AFTER = EQ_STRAIGHT;
     static constexpr bool LOOP = EQ && !LATE_TAPS && !SDR_EQ_NOLOOP && GROUP == 1 && !EQ_STRAIGHT && !EPILOGUE_TAPS;

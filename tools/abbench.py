@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Same-buffer A/B of two builds of libsdr_amd.so: both libraries are loaded into ONE process and time the
+receive kernel alternately on the SAME tensors, so that neither the box nor the placement of the buffers
+(profiles/r2_eq_placement_lottery.txt) can tell them apart.
+usage: abbench.py libA.so libB.so --cases n_fft:bps[:eq][:hard][:nollr] ...   (prints % of 8 TB/s for A, B, A - B)"""
+import argparse
+import ctypes
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("lib_a")
+    ap.add_argument("lib_b")
+    ap.add_argument("--cases", nargs="+", required=True)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--rounds", type=int, default=3)
+    args = ap.parse_args()
+    import torch
+    from sdr_amd import capi
+    from sdr_amd.ops import Context
+
+    def ctx_of(path):
+        capi._lib = None
+        capi.LIB_PATH = os.path.abspath(path)
+        c = Context(0)          # binds the freshly loaded library
+        return c
+    ca, cb = ctx_of(args.lib_a), ctx_of(args.lib_b)
+    assert ca.lib is not cb.lib
+    g = torch.Generator(device="cuda").manual_seed(1)
+    for case in args.cases:
+        parts = case.split(":")
+        n, bps = int(parts[0]), int(parts[1])
+        with_eq, with_hard, no_llr = "eq" in parts[2:], "hard" in parts[2:], "nollr" in parts[2:]
+        cp = n // 4
+        bytes_sym = 8 * n + (0 if no_llr else 4 * n * bps) + (n * bps // 8 if with_hard else 0)
+        n_sym = max(1024, min(1 << 20, (8 << 30) // (bytes_sym + 8 * cp)))
+        rx = torch.randn((n_sym, (n + cp) * 2), dtype=torch.float32, device="cuda", generator=g).mul_((2.0 * n) ** -0.5).view(torch.complex64)
+        eq = wgt = None
+        per = 0
+        if with_eq:
+            per = 14
+            n_sets = (n_sym + per - 1) // per
+            eq = torch.randn((n_sets, n * 2), dtype=torch.float32, device="cuda", generator=g).view(torch.complex64)
+            wgt = torch.rand((n_sets, n), dtype=torch.float32, device="cuda", generator=g)
+        out = None if no_llr else torch.empty((n_sym, n, bps), dtype=torch.float32, device="cuda")
+        hard = torch.empty(n_sym * n * bps // 8, dtype=torch.uint8, device="cuda") if with_hard else None
+
+        def rate(c):
+            step = lambda: c.demod(rx, n, cp, bps, eq=eq, llr_weight=(wgt if wgt is not None else 1.5), sym_per_set=per, out_llr=out, want_llr=not no_llr, out_hard=hard)
+            for _ in range(3):
+                step()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.steps):
+                step()
+            e1.record()
+            torch.cuda.synchronize()
+            return bytes_sym * n_sym / (e0.elapsed_time(e1) / args.steps / 1e3) / 8e12 * 100
+        for c in (ca, cb):           # first touch of fresh buffers
+            rate(c)
+        ra, rb = [], []
+        for _ in range(args.rounds):
+            ra.append(rate(ca))
+            rb.append(rate(cb))
+        ma, mb = sorted(ra)[len(ra) // 2], sorted(rb)[len(rb) // 2]
+        print(f"case {case:>14s}  A {ma:5.1f}  B {mb:5.1f}  A-B {ma - mb:+5.1f}   (A {' '.join(f'{v:.1f}' for v in ra)} | B {' '.join(f'{v:.1f}' for v in rb)})", flush=True)
+        del rx, eq, wgt, out, hard
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
