@@ -555,8 +555,19 @@ struct RxShape {
 #ifdef SDR_EQ_TAPS_AFTER
     static constexpr bool EQ_STRAIGHT_RULE = true;
 #else
-    static constexpr bool EQ_STRAIGHT_RULE = FULL ? (LOG2N == 11)      // with hard bits / counters: +2 at N = 2048, -3.6 at 1024, -1.6 at 4096
-                                                  : (eq_form() == 1);
+    // every-output variants (hard bits, counters beside LLRs; same tool, N:bps:eq:hard): straight wins +1.5 to +7.1 at
+    // 64 / 256 from 64-QAM, 256 everywhere, 1024 at 256-QAM, 2048 from 16-QAM to 256-QAM; loses 1.4 to 5.4 at 512, 4096, QPSK
+    static constexpr bool full_straight()
+    {
+        switch (LOG2N) {
+            case 6: case 7: return BPS >= 6 && BPS <= 8;
+            case 8: return BPS >= 2 && BPS <= 8;
+            case 10: return BPS == 8;
+            case 11: return BPS >= 4 && BPS <= 8;
+            default: return false;
+        }
+    }
+    static constexpr bool EQ_STRAIGHT_RULE = FULL ? full_straight() : (eq_form() == 1);
 #endif
     // N = 8192 (E = 32): 96 tap registers beside 64 of data and the last pass's twiddles do not fit 256
     // (one wave per SIMD, or spills with late taps); there the epilogue reads each register group's taps
