@@ -398,6 +398,9 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 #ifndef SDR_LATE_TAPS_FULL
 #define SDR_LATE_TAPS_FULL 0
 #endif
+#ifndef SDR_NT_EQ
+#define SDR_NT_EQ -1     // -1: per-size rule, 0: never, 1: every tap-reading variant
+#endif
 #ifndef SDR_EQ_FORM_12_10
 #define SDR_EQ_FORM_12_10 1
 #endif
@@ -576,6 +579,15 @@ struct RxShape {
 #define SDR_EPILOGUE_TAPS_13 1      // same-box A/B: +0.2 to +9.5 points over one wave per SIMD with held taps (profiles/r2_eq_straight_line_ab.txt)
 #endif
     static constexpr bool EPILOGUE_TAPS = EQ && DEMAP && !FULL && GROUP == 1 && eq_form() == 3 && SDR_EPILOGUE_TAPS_13;
+    // Non-temporal sample loads in the tap-reading variants: the samples are read once, the taps of a set
+    // by up to 14 workgroups.  Same-buffer A/B (tools/abbench.py): +0.4 to +2.5 points at N = 1024, +0.9 to
+    // +11.3 at N = 8192 (64-QAM: 47.7 -> 59.0 %), level (-0.5 ... +0.2) at the other sizes, which keep plain
+    // loads; the variants without taps lose up to 1.7 points with them.
+#ifdef SDR_NT_LOADS
+    static constexpr bool NT_SAMPLES = true;
+#else
+    static constexpr bool NT_SAMPLES = EQ && DEMAP && (SDR_NT_EQ == 1 || (SDR_NT_EQ < 0 && (LOG2N == 10 || LOG2N == 13)));
+#endif
     static constexpr bool EQ_STRAIGHT = EQ && DEMAP && !LATE_TAPS && GROUP == 1 && EQ_STRAIGHT_RULE && !SDR_EQ_FORCE_LOOP;
     static constexpr bool TAPS_AFTER = EQ_STRAIGHT;
     static constexpr bool LOOP = EQ && !LATE_TAPS && !SDR_EQ_NOLOOP && GROUP == 1 && !EQ_STRAIGHT && !EPILOGUE_TAPS;
@@ -667,11 +679,13 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG * GROUP)
                 dst[q] = src[idx0];
             } else {
                 // register bit kR[0] is the group bit: adjacent input samples
-#ifdef SDR_NT_LOADS
-                const sdr_v4f v = __builtin_nontemporal_load(reinterpret_cast<const sdr_v4f*>(src + idx0));
-#else
-                const float4 v = *reinterpret_cast<const float4*>(src + idx0);
-#endif
+                float4 v;
+                if constexpr (S::NT_SAMPLES) {
+                    const sdr_v4f q = __builtin_nontemporal_load(reinterpret_cast<const sdr_v4f*>(src + idx0));
+                    v = make_float4(q.x, q.y, q.z, q.w);
+                } else {
+                    v = *reinterpret_cast<const float4*>(src + idx0);
+                }
                 dst[q] = make_float2(v.x, v.y);
                 dst[q | (1 << P::kR[0])] = make_float2(v.z, v.w);
             }
