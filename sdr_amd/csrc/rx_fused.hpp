@@ -523,6 +523,9 @@ struct RxShape {
     //   3  straight-line, taps read in the epilogue where they are used (EPILOGUE_TAPS; N = 8192)
     static constexpr int eq_form()
     {
+#ifdef SDR_EQ_FORM_ALL      // experiment: one form everywhere
+        return SDR_EQ_FORM_ALL;
+#endif
         switch (LOG2N) {
             case 6: return BPS == 2 ? 0 : 1;
             case 7: return 1;
@@ -882,11 +885,14 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG * GROUP)
                     const float2* dummy = p.rx + static_cast<size_t>(sym) * in_stride;
                     const float2* eq_src = p.eq ? p.eq + tap_set * N : dummy;
                     const float* wgt_src = p.wgt ? p.wgt + tap_set * N : reinterpret_cast<const float*>(dummy);
-                    static_assert(GO == 2, "pairs of adjacent bins");
-                    const float4 v = *reinterpret_cast<const float4*>(eq_src + k);
-                    const float2 u = *reinterpret_cast<const float2*>(wgt_src + k);
-                    epi_eq[0] = make_float2(v.x, v.y); epi_eq[1] = make_float2(v.z, v.w);
-                    epi_w[0] = u.x; epi_w[1] = u.y;
+                    if constexpr (GO == 2) {
+                        const float4 v = *reinterpret_cast<const float4*>(eq_src + k);
+                        const float2 u = *reinterpret_cast<const float2*>(wgt_src + k);
+                        epi_eq[0] = make_float2(v.x, v.y); epi_eq[1] = make_float2(v.z, v.w);
+                        epi_w[0] = u.x; epi_w[1] = u.y;
+                    } else {
+                        static_for<GO>([&](auto G) { constexpr int g = G; epi_eq[g] = eq_src[k + g]; epi_w[g] = wgt_src[k + g]; });
+                    }
                 }
                 static_for<GO>([&](auto G) {
                     constexpr int g = G;
