@@ -505,7 +505,7 @@ struct RxShape {
         switch (LOG2N) {
             case 6: return BPS <= 8 ? (BPS == 4 ? 9 : 8) : 0;
             case 7: return BPS <= 4 ? 6 : BPS == 6 ? 7 : BPS == 8 ? 8 : 0;
-            case 8: return BPS <= 4 ? 6 : BPS == 6 ? 8 : BPS == 8 ? 10 : 0;
+            case 8: return BPS == 2 ? 0 : BPS == 4 ? 6 : BPS == 6 ? 8 : BPS == 8 ? 10 : 0;      // QPSK: -2.1 with the throttle (same-buffer A/B)
             case 9: return BPS == 2 ? 14 : BPS <= 8 ? 12 : 0;
             case 10: return BPS == 4 ? 10 : BPS == 6 ? 9 : BPS == 8 ? 12 : 0;
             default: return 0;
