@@ -97,7 +97,7 @@ int rx_fused_launch(sdr_ctx* ctx, const sdr_demod_args& a, const RxWorkspace* ws
     p.sym_per_set = a.sym_per_set;
     p.w0 = a.llr_weight0;
     p.inorm = std::sqrt(static_cast<float>(grid_energy(static_cast<int>(a.mod))));
-    const bool full = a.d_hard || a.d_fft || a.d_counters || !a.d_llr || (a.mod == 1 && (a.d_eq || a.d_llr_weight));      // BPSK with taps: full variant only
+    const bool full = a.d_hard || a.d_fft || a.d_counters || !a.d_llr;
     const bool hard_only = a.d_hard && !a.d_llr && !a.d_fft && !a.d_counters && !a.d_eq && a.mod != 1;   // weights do not matter to nearest()
     int variant = hard_only ? 4 : (full ? 2 : 0) | ((a.d_eq || a.d_llr_weight) ? 1 : 0);
 #ifdef SDR_GROUP_VARIANTS

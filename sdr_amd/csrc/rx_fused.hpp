@@ -398,6 +398,9 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 #ifndef SDR_LATE_TAPS_FULL
 #define SDR_LATE_TAPS_FULL 0
 #endif
+#ifndef SDR_EQ_FORM_BPSK
+#define SDR_EQ_FORM_BPSK 0
+#endif
 #ifndef SDR_NT_EQ
 #define SDR_NT_EQ -1     // -1: per-size rule, 0: never, 1: every tap-reading variant
 #endif
@@ -526,6 +529,7 @@ struct RxShape {
 #ifdef SDR_EQ_FORM_ALL      // experiment: one form everywhere
         return SDR_EQ_FORM_ALL;
 #endif
+        if (BPS == 1) return LOG2N == 13 ? 3 : SDR_EQ_FORM_BPSK;
         switch (LOG2N) {
             case 6: return BPS == 2 ? 0 : 1;
             case 7: return 1;

@@ -39,8 +39,9 @@ int SDR_CAT(rx_fused_dispatch_, SDR_LOG2N)(sdr_ctx* ctx, const RxParams& p, int 
     }
     switch (mod) {
         case 0: return launch_rx_fused<L, 0, 0, true, false>(ctx, p);
-        case 1:                                                       // BPSK: LLR-only without taps, or the full variants
+        case 1:                                                       // BPSK: the LLR-only variants, or the every-output ones (no hard-bits-only form)
             if (variant == 0) return launch_rx_fused<L, 1, 0, false, false>(ctx, p);
+            if (variant == 1) return launch_rx_fused<L, 1, 0, false, true>(ctx, p);
             return (variant & 1) ? launch_rx_fused<L, 1, 0, true, true>(ctx, p) : launch_rx_fused<L, 1, 0, true, false>(ctx, p);
         case 2: SDR_RX_CASE(1, 1)
         case 4: SDR_RX_CASE(2, 2)
