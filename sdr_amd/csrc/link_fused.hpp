@@ -462,16 +462,16 @@ __device__ __forceinline__ void mc_body(const McWork& p, unsigned char* lds, con
                 n_bit += __popc(diff);
                 n_sym_err += (diff != 0);
                 if constexpr (HARD) continue;
-                unsigned two = 0;
+                unsigned two = 0, negative = 0;
                 static_for<BPS>([&](auto B) {
                     constexpr int b = B;
-                    float a = fabsf(l[b]) * 1024.0f;
-                    a = (a < 1073741824.0f) ? a : 1073741824.0f;
+                    const float a = fminf(fabsf(l[b]) * 1024.0f, 1073741824.0f);      // NaN -> 2^30, like the compare it replaces
                     // a in [0, 2^30]: the 32-bit truncation is the 64-bit one; two of them fit 32 bits
                     if constexpr (b % 2 == 0) two = static_cast<unsigned>(static_cast<int>(a));
                     else { c_abs += two + static_cast<unsigned>(static_cast<int>(a)); two = 0; }
-                    n_sign += (((ref >> (BPS - 1 - b)) & 1u) != (l[b] < 0.0f ? 1u : 0u));
+                    negative = (negative << 1) | (l[b] < 0.0f ? 1u : 0u);
                 });
+                n_sign += __popc(negative ^ ref);
                 c_abs += two;
             }
         }

@@ -995,16 +995,18 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG * GROUP)
                             const unsigned diff = ref ^ idx[g];
                             n_bit += __popc(diff);
                             n_sym_err += (diff != 0);
+                            unsigned negative = 0;      // bit BPS-1-b = (LLR b < 0): the same order as the reference bits
                             static_for<BPS>([&](auto B) {
                                 constexpr int b = B;
                                 const float lv = l[g * BPS + b];
-                                float a = fabsf(lv) * 1024.0f;
-                                a = (a < 1073741824.0f) ? a : 1073741824.0f;
+                                // min(|LLR| * 1024, 2^30); fminf returns the other operand for a NaN, like the compare it replaces
+                                const float a = fminf(fabsf(lv) * 1024.0f, 1073741824.0f);
                                 // a in [0, 2^30]: the 32-bit truncation is the 64-bit one
                                 if constexpr ((g * BPS + b) % 2 == 1) { n_abs += static_cast<unsigned>(static_cast<int>(a)); wide_abs += n_abs; n_abs = 0; }
                                 else n_abs = static_cast<unsigned>(static_cast<int>(a));
-                                n_sign += (((ref >> (BPS - 1 - b)) & 1u) != (lv < 0.0f ? 1u : 0u));
+                                negative = (negative << 1) | (lv < 0.0f ? 1u : 0u);
                             });
+                            n_sign += __popc(negative ^ ref);
                         });
                         c_bit += n_bit; c_sym += n_sym_err; c_sign += n_sign; c_abs += wide_abs + n_abs;
                     }
