@@ -28,12 +28,11 @@ DEFAULT_MAX_DB = {2: 10, 4: 14, 6: 18, 8: 24}
 
 
 # VALU-issue cost of ONE OFDM symbol in the fused Monte-Carlo kernel at n_fft = 1024, in SIMD cycles:
-# instruction-class counts from rocprofv3 PMC passes (profiles/r2_pmc_instruction_classes_65536sym.txt and
-# the same passes for the other modulations) weighted with the issue cost tools/valubench measured on
+# instruction-class counts from rocprofv3 PMC passes (profiles/r2_pmc_instruction_classes_mc_final_65536sym.txt) weighted with the issue cost tools/valubench measured on
 # MI355X (profiles/r2_valubench_issue_cost.txt: VOP1/VOP2 2.15, packed fp32 4.1, v_mad_u64_u32 4.6,
 # transcendental 10 cycles per wave64 instruction).  Key: bits per subcarrier.
-VALU_ISSUE_CYCLES_PER_SYMBOL_1024 = {1: 11680, 2: 12827, 4: 14373, 6: 16390, 8: 19645, 10: 25891}
-VALU_LANE_INSTR_PER_SYMBOL_1024 = {1: 244638, 2: 274592, 4: 313818, 6: 369901, 8: 462832, 10: 644773}
+VALU_ISSUE_CYCLES_PER_SYMBOL_1024 = {1: 11577, 2: 12589, 4: 14031, 6: 15838, 8: 18987, 10: 24290}
+VALU_LANE_INSTR_PER_SYMBOL_1024 = {1: 241566, 2: 268444, 4: 309204, 6: 361811, 8: 454392, 10: 611032}
 # the same for the hard-only bodies (SDR_POINT_HARD_ONLY; profiles/r2_pmc_instruction_classes_mc_hard_only_65536sym.txt)
 VALU_ISSUE_CYCLES_PER_SYMBOL_1024_HARD = {1: 11413, 2: 12086, 4: 12059, 6: 12151, 8: 12241, 10: 12530}
 VALU_LANE_INSTR_PER_SYMBOL_1024_HARD = {1: 236032, 2: 252344, 4: 253783, 6: 256510, 8: 259214, 10: 267751}
