@@ -29,13 +29,13 @@ DEFAULT_MAX_DB = {2: 10, 4: 14, 6: 18, 8: 24}
 
 # VALU-issue cost of ONE OFDM symbol in the fused Monte-Carlo kernel at n_fft = 1024, in SIMD cycles:
 # instruction-class counts from rocprofv3 PMC passes (profiles/r2_pmc_instruction_classes_mc_final_65536sym.txt) weighted with the issue cost tools/valubench measured on
-# MI355X (profiles/r2_valubench_issue_cost.txt: VOP1/VOP2 2.15, packed fp32 4.1, v_mad_u64_u32 4.6,
-# transcendental 10 cycles per wave64 instruction).  Key: bits per subcarrier.
-VALU_ISSUE_CYCLES_PER_SYMBOL_1024 = {1: 11577, 2: 12589, 4: 14031, 6: 15838, 8: 18987, 10: 24290}
-VALU_LANE_INSTR_PER_SYMBOL_1024 = {1: 241566, 2: 268444, 4: 309204, 6: 361811, 8: 454392, 10: 611032}
+# MI355X (profiles/r2_valubench_issue_cost.txt: VOP1/VOP2 2.15, v_mad_u64_u32 4.6, transcendental 10 cycles
+# per wave64 instruction; the library is built without packed fp32, which would cost 4.1).  Key: bits per subcarrier.
+VALU_ISSUE_CYCLES_PER_SYMBOL_1024 = {1: 9487, 2: 10519, 4: 11933, 6: 13765, 8: 16914, 10: 22251}
+VALU_LANE_INSTR_PER_SYMBOL_1024 = {1: 261448, 2: 292172, 4: 333080, 6: 386437, 8: 479018, 10: 636723}
 # the same for the hard-only bodies (SDR_POINT_HARD_ONLY; profiles/r2_pmc_instruction_classes_mc_hard_only_65536sym.txt)
-VALU_ISSUE_CYCLES_PER_SYMBOL_1024_HARD = {1: 11413, 2: 12086, 4: 12059, 6: 12151, 8: 12241, 10: 12530}
-VALU_LANE_INSTR_PER_SYMBOL_1024_HARD = {1: 236032, 2: 252344, 4: 253783, 6: 256510, 8: 259214, 10: 267751}
+VALU_ISSUE_CYCLES_PER_SYMBOL_1024_HARD = {1: 9182, 2: 9765, 4: 9901, 6: 10045, 8: 10193, 10: 10391}
+VALU_LANE_INSTR_PER_SYMBOL_1024_HARD = {1: 253544, 2: 270908, 4: 274954, 6: 279218, 8: 283632, 10: 289512}
 SIMD_CYCLES_PER_S = 256 * 4 * 2.4e9      # 256 CUs x 4 SIMDs at the 2.4 GHz peak engine clock (MI355X_MICROARCH.md)
 
 
