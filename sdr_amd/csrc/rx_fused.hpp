@@ -405,7 +405,7 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 #define SDR_NT_EQ -1     // -1: per-size rule, 0: never, 1: every tap-reading variant
 #endif
 #ifndef SDR_EQ_FORM_12_10
-#define SDR_EQ_FORM_12_10 1
+#define SDR_EQ_FORM_12_10 0
 #endif
 #ifndef SDR_LATE_13
 #define SDR_LATE_13 0
@@ -532,11 +532,11 @@ struct RxShape {
         if (BPS == 1) return LOG2N == 13 ? 3 : SDR_EQ_FORM_BPSK;
         switch (LOG2N) {
             case 6: return BPS == 2 ? 0 : 1;
-            case 7: return 1;
-            case 8: return BPS <= 4 ? 0 : 1;
+            case 7: return BPS == 10 ? 0 : 1;
+            case 8: return (BPS <= 4 || BPS == 10) ? 0 : 1;
             case 10: return (BPS == 2 || BPS == 10) ? 0 : 1;
             case 11: return (BPS == 2 || BPS == 10) ? 0 : BPS == 4 ? 1 : 2;
-            case 12: return BPS <= 4 ? 0 : BPS == 10 ? SDR_EQ_FORM_12_10 : 2;
+            case 12: return BPS <= 4 ? 0 : BPS == 10 ? SDR_EQ_FORM_12_10 : 2;      // 1024-QAM: the run of two again since the unpacked build (-2.2 with the straight form)
             case 13: return 3;
             default: return 0;      // N = 512: the run of two
         }
