@@ -571,9 +571,9 @@ struct RxShape {
     {
         switch (LOG2N) {
             case 6: case 7: return BPS >= 6 && BPS <= 8;
-            case 8: return BPS >= 2 && BPS <= 8;
+            case 8: return BPS >= 4 && BPS <= 8;
             case 10: return BPS == 8;
-            case 11: return BPS >= 4 && BPS <= 8;
+            case 11: return BPS >= 6 && BPS <= 8;
             default: return false;
         }
     }
