@@ -467,13 +467,28 @@ struct RxShape {
     static constexpr int REF_SYM_BYTES = N * (DEMAP ? BPS : 8) / 8;      // reference bits of one symbol
     static constexpr int REF_BYTES = (FULL && DEMAP) ? REF_SYM_BYTES * SPW : 0;
     static constexpr int CHUNK = O::kGroupOut * BPS;                     // LLR floats per lane per output block
+    // Several symbols per wave (N <= 256): one output block is a run of TPS * CHUNK floats per symbol.  Where that
+    // run is not a whole number of 128-byte lines (N = 64 at QPSK / 64-QAM / 1024-QAM: 64 / 192 / 320 bytes) two
+    // (BPSK: four) consecutive blocks are staged together, so that every store covers whole lines (128 / 384 / 640 bytes per symbol).
+#ifndef SDR_STG_PAIRS
+#define SDR_STG_PAIRS 1
+#endif
+    static constexpr int RUN_BYTES = O::kTPS * CHUNK * 4;
+    static constexpr int stg_blocks()
+    {
+        if (!(SDR_STG_PAIRS && DEMAP && !HARDONLY && SPW > 1 && O::kWG == 64 && GROUP == 1 && stage_stride_bytes(CHUNK) == CHUNK * 4)) return 1;
+        for (int nb = 1; nb <= 4; nb *= 2)
+            if ((nb * RUN_BYTES) % 128 == 0 && (O::kE / O::kGroupOut) % nb == 0) return nb;
+        return 1;
+    }
+    static constexpr int STG_BLOCKS = stg_blocks();
 #ifdef SDR_NO_SMALL_STAGE
     static constexpr bool STAGE = DEMAP && !HARDONLY && SPW == 1 && stage_wanted(CHUNK);
 #else
-    static constexpr bool STAGE = DEMAP && !HARDONLY && stage_wanted(CHUNK);
+    static constexpr bool STAGE = DEMAP && !HARDONLY && (stage_wanted(CHUNK) || STG_BLOCKS > 1);
 #endif
     static constexpr int STG_STRIDE = stage_stride_bytes(CHUNK);
-    static constexpr int STG_WAVE_BYTES = STAGE ? 64 * STG_STRIDE : 0;
+    static constexpr int STG_WAVE_BYTES = STAGE ? 64 * STG_STRIDE * STG_BLOCKS : 0;
     static constexpr int STG_BYTES = STG_WAVE_BYTES * (O::kWG / 64);
     // The staging strips reuse the exchange region when they fit: it is dead between the last
     // exchange read and the next symbol's first exchange write.  Multi-wave workgroups need a
@@ -930,14 +945,24 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG * GROUP)
                         // a strip without padding is linear memory: 16-byte vectors may straddle lanes
                         constexpr bool LINEAR = SDR_LINEAR_STRIP && STG_STRIDE == CHUNK * 4 && (64 * CHUNK) % 4 == 0;
                         constexpr int VW = (CHUNK % 4 == 0 || LINEAR) ? 4 : 2;   // floats per vector
-                        constexpr int NV = 64 * CHUNK / VW;                      // vectors per wave and block
+                        constexpr int NB = S::STG_BLOCKS;                        // blocks staged together (N = 64: two)
+                        constexpr int hb = h % NB, h0 = h - hb;
+                        constexpr int NV = 64 * CHUNK * NB / VW;                 // vectors per wave and staged group
                         constexpr int VPL = CHUNK / VW;                          // vectors per lane (padded strips)
                         const int lane = tid & 63;
                         float* stg = reinterpret_cast<float*>(lds + STG_OFF + (GROUP > 1 ? gslot * SYM_BYTES : 0) + (tid >> 6) * STG_WAVE_BYTES);
-                        store_floats<CHUNK>(stg + lane * (STG_STRIDE / 4), l);
+                        if constexpr (NB == 1) {
+                            store_floats<CHUNK>(stg + lane * (STG_STRIDE / 4), l);
+                        } else {
+                            // symbol-major, the symbol's NB blocks one behind the other: memory order
+                            static_assert(LINEAR && SPW > 1 && O::reg_pos(LAST, (h0 + NB - 1) * GO) == O::reg_pos(LAST, h0 * GO) + (NB - 1) * TPS * GO
+                                              && O::reg_pos(LAST, (h0 + 1) * GO) == O::reg_pos(LAST, h0 * GO) + TPS * GO, "staged blocks are adjacent in memory");
+                            store_floats<CHUNK>(stg + (((lane / TPS) * NB + hb) * TPS + (lane % TPS)) * CHUNK, l);
+                        }
+                        if constexpr (hb == NB - 1) {
                         __builtin_amdgcn_wave_barrier();
                         constexpr int gbits = O::kLogE - P::kR[LAST];
-                        float* gbase = p.llr + (bin0 + O::reg_pos(LAST, h * GO) + ((tid & ~63) << gbits)) * BPS;
+                        float* gbase = p.llr + (bin0 + O::reg_pos(LAST, h0 * GO) + ((tid & ~63) << gbits)) * BPS;
                         static_for<(NV + 63) / 64>([&](auto I) {
                             constexpr int i = I;
                             const int v = i * 64 + lane;
@@ -949,12 +974,12 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG * GROUP)
                             if constexpr (SPW == 1) {
                                 dst = gbase + v * VW;
                             } else {
-                                constexpr int RUN = TPS * CHUNK;                 // floats per symbol in this block
+                                constexpr int RUN = TPS * CHUNK * NB;            // floats per symbol in this staged group
                                 static_assert(RUN % VW == 0, "vectors do not straddle symbols");
                                 const int s_ = (v * VW) / RUN, off = (v * VW) % RUN;
                                 const unsigned long long dsym = grp * SPW + s_;
                                 ok = ok && dsym < p.n_sym;
-                                dst = p.llr + (static_cast<size_t>(dsym) * N + O::reg_pos(LAST, h * GO)) * BPS + off;
+                                dst = p.llr + (static_cast<size_t>(dsym) * N + O::reg_pos(LAST, h0 * GO)) * BPS + off;
                             }
                             if (ok) {
                                 if constexpr (VW == 4) {
@@ -967,6 +992,7 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG * GROUP)
                             }
                         });
                         __builtin_amdgcn_wave_barrier();
+                        }      // last block of the staged group
                     }
                 } else if constexpr (!HARDONLY) {
                     if (p.llr && active) store_floats<GO * BPS>(p.llr + (bin0 + k) * BPS, l);
