@@ -473,6 +473,9 @@ struct RxShape {
 #ifndef SDR_STG_PAIRS
 #define SDR_STG_PAIRS 1
 #endif
+#ifndef SDR_BINS_STAGED
+#define SDR_BINS_STAGED 1
+#endif
     static constexpr int RUN_BYTES = O::kTPS * CHUNK * 4;
     static constexpr int stg_blocks()
     {
@@ -877,7 +880,41 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG * GROUP)
         // ---- epilogue: bins are in natural order, k = reg_pos(LAST, m) | pos_last ----
         constexpr int GO = O::kGroupOut;   // adjacent bins held in registers m = GO*h + (0..GO-1)
         const size_t bin0 = static_cast<size_t>(sym) * N;
-        if constexpr (!DEMAP || FULL) {
+        // Bins out with several symbols per wave whose per-block run (TPS * GO bins) is half a cache line (N = 64): two
+        // consecutive blocks go through the dead exchange region (one-wave workgroups: LDS ops are in order) so that
+        // every store covers whole 128-byte lines.
+        constexpr bool BINS_STAGED = SDR_BINS_STAGED && SPW > 1 && O::kWG == 64 && GROUP == 1 && (TPS * GO * 8) % 128 != 0 && (2 * TPS * GO * 8) % 128 == 0
+                                     && (E / GO) % 2 == 0 && 64 * GO * 2 * 2 * 4 <= DATA_BYTES;
+        if constexpr ((!DEMAP || FULL) && BINS_STAGED) {
+            if (p.fft) {
+                constexpr int CB = GO * 2, NBB = 2;                      // floats per lane and block, blocks per group
+                float* stg = reinterpret_cast<float*>(lds_data);
+                const int lane = tid & 63;
+                static_for<E / GO>([&](auto Hh) {
+                    constexpr int h = Hh, hb = h % NBB, h0 = h - hb;
+                    static_assert(O::reg_pos(LAST, (h0 + 1) * GO) == O::reg_pos(LAST, h0 * GO) + TPS * GO, "paired blocks are adjacent in memory");
+                    float* mine = stg + (((lane / TPS) * NBB + hb) * TPS + (lane % TPS)) * CB;
+                    static_for<GO>([&](auto G) { constexpr int g = G; *reinterpret_cast<float2*>(mine + 2 * g) = x[h * GO + g]; });
+                    if constexpr (hb == NBB - 1) {
+                        __builtin_amdgcn_wave_barrier();
+                        constexpr int RUN = TPS * CB * NBB;                  // floats per symbol in the group
+                        constexpr int NV = 64 * CB * NBB / 4;
+                        static_assert(RUN % 4 == 0 && NV % 64 == 0, "whole vectors, whole wave");
+                        static_for<NV / 64>([&](auto I) {
+                            constexpr int i = I;
+                            const int v = i * 64 + lane;
+                            const int s_ = (v * 4) / RUN, off = (v * 4) % RUN;
+                            const unsigned long long dsym = grp * SPW + s_;
+                            if (dsym < p.n_sym) {
+                                const float4 q4 = *reinterpret_cast<const float4*>(stg + v * 4);
+                                *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.fft + static_cast<size_t>(dsym) * N + O::reg_pos(LAST, h0 * GO)) + off) = q4;
+                            }
+                        });
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                });
+            }
+        } else if constexpr (!DEMAP || FULL) {
             if (p.fft && active) {
                 static_for<E / GO>([&](auto Hh) {
                     constexpr int h = Hh;

@@ -2,7 +2,7 @@
 """Same-buffer A/B of two builds of libsdr_amd.so: both libraries are loaded into ONE process and time the
 receive kernel alternately on the SAME tensors, so that neither the box nor the placement of the buffers
 (profiles/r2_eq_placement_lottery.txt) can tell them apart.
-usage: abbench.py libA.so libB.so --cases n_fft:bps[:eq][:hard][:nollr] ...   (prints % of 8 TB/s for A, B, A - B)"""
+usage: abbench.py libA.so libB.so --cases n_fft:bps[:eq][:hard][:nollr][:fft] | n_fft:bins ...   (prints % of 8 TB/s for A, B, A - B)"""
 import argparse
 import ctypes
 import os
@@ -33,10 +33,12 @@ def main():
     g = torch.Generator(device="cuda").manual_seed(1)
     for case in args.cases:
         parts = case.split(":")
-        n, bps = int(parts[0]), int(parts[1])
-        with_eq, with_hard, no_llr = "eq" in parts[2:], "hard" in parts[2:], "nollr" in parts[2:]
+        n = int(parts[0])
+        bins_only = parts[1] == "bins"                      # ofdm::rx: strip the prefix, transform, bins out
+        bps = 2 if bins_only else int(parts[1])
+        with_eq, with_hard, no_llr, with_fft = "eq" in parts[2:], "hard" in parts[2:], "nollr" in parts[2:] or bins_only, "fft" in parts[2:]
         cp = n // 4
-        bytes_sym = 8 * n + (0 if no_llr else 4 * n * bps) + (n * bps // 8 if with_hard else 0)
+        bytes_sym = 8 * n + (0 if no_llr else 4 * n * bps) + (n * bps // 8 if with_hard else 0) + (8 * n if with_fft or bins_only else 0)
         n_sym = max(1024, min(1 << 20, (8 << 30) // (bytes_sym + 8 * cp)))
         rx = torch.randn((n_sym, (n + cp) * 2), dtype=torch.float32, device="cuda", generator=g).mul_((2.0 * n) ** -0.5).view(torch.complex64)
         eq = wgt = None
@@ -48,9 +50,13 @@ def main():
             wgt = torch.rand((n_sets, n), dtype=torch.float32, device="cuda", generator=g)
         out = None if no_llr else torch.empty((n_sym, n, bps), dtype=torch.float32, device="cuda")
         hard = torch.empty(n_sym * n * bps // 8, dtype=torch.uint8, device="cuda") if with_hard else None
+        bins = torch.empty((n_sym, n), dtype=torch.complex64, device="cuda") if with_fft or bins_only else None
 
         def rate(c):
-            step = lambda: c.demod(rx, n, cp, bps, eq=eq, llr_weight=(wgt if wgt is not None else 1.5), sym_per_set=per, out_llr=out, want_llr=not no_llr, out_hard=hard)
+            if bins_only:
+                step = lambda: capi.check(c.lib.sdr_ofdm_rx_c32(c._h, rx.data_ptr(), n, cp, n_sym, bins.data_ptr()))
+            else:
+                step = lambda: c.demod(rx, n, cp, bps, eq=eq, llr_weight=(wgt if wgt is not None else 1.5), sym_per_set=per, out_llr=out, want_llr=not no_llr, out_hard=hard, out_fft=bins)
             for _ in range(3):
                 step()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -68,7 +74,7 @@ def main():
             rb.append(rate(cb))
         ma, mb = sorted(ra)[len(ra) // 2], sorted(rb)[len(rb) // 2]
         print(f"case {case:>14s}  A {ma:5.1f}  B {mb:5.1f}  A-B {ma - mb:+5.1f}   (A {' '.join(f'{v:.1f}' for v in ra)} | B {' '.join(f'{v:.1f}' for v in rb)})", flush=True)
-        del rx, eq, wgt, out, hard
+        del rx, eq, wgt, out, hard, bins
         torch.cuda.empty_cache()
 
 
