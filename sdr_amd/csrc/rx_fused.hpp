@@ -333,6 +333,7 @@ __device__ __forceinline__ void fft_run(float2 (&x)[PlanOps<LOG2N>::kE], unsigne
         symbol_sync<WAVE_SYNC>();
         static_for<E>([&](auto M) { constexpr int m = M; x[m] = *reinterpret_cast<const float2*>(lds_data + a.rd1 + O::reg_addr(1, 2, m)); });
     }
+    if constexpr (LATE_AT == 2) late();      // behind the last exchange read: nothing but the last butterflies left to cover it
     static_for<P::kR[LAST]>([&](auto S) {
         constexpr int s = S;
         constexpr int c = P::kC0[LAST] + s;
@@ -343,6 +344,7 @@ __device__ __forceinline__ void fft_run(float2 (&x)[PlanOps<LOG2N>::kE], unsigne
             bfly<CONJ>(x[m0], x[m1], w.last[O::last_tw_offset(s) + O::pext(m0, mask)]);
         });
     });
+    if constexpr (LATE_AT == 3) late();
 }
 
 typedef float sdr_v4f __attribute__((ext_vector_type(4)));
@@ -410,6 +412,15 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 #ifndef SDR_LATE_13
 #define SDR_LATE_13 0
 #endif
+#ifndef SDR_EQ_FORM_13
+#define SDR_EQ_FORM_13 3
+#endif
+#ifndef SDR_LATE_AT_13
+#define SDR_LATE_AT_13 2
+#endif
+#ifndef SDR_EPI_AHEAD
+#define SDR_EPI_AHEAD 4      // same-buffer A/B at N = 8192: BPSK 32.4 -> 49.3 %, QPSK 42.7 -> 56.6, 16-QAM 50.3 -> 60.0, the others +0.2 to +1.0 (8: level, 1024-QAM -1.6)
+#endif
 #ifndef SDR_LATE_13_WPE
 #define SDR_LATE_13_WPE 2
 #endif
@@ -462,10 +473,20 @@ struct RxShape {
 #ifndef SDR_HARD_IDX_ALIAS
 #define SDR_HARD_IDX_ALIAS 1
 #endif
-    static constexpr bool IDX_ALIAS = HARDONLY && SDR_HARD_IDX_ALIAS;
-    static constexpr int IDX_BYTES = (HARD_PATH && !IDX_ALIAS) ? N * SPW * static_cast<int>(sizeof(idx_t)) : 0;
+    // The every-output variants do the same from SDR_FULL_IDX_ALIAS_FROM on (behind the staging strips, which
+    // alias the region too): at N = 8192 it is the difference between one and two workgroups per CU.
+#ifndef SDR_FULL_IDX_ALIAS_FROM
+#define SDR_FULL_IDX_ALIAS_FROM 13
+#endif
+    static constexpr bool IDX_ALIAS = HARD_PATH && SDR_HARD_IDX_ALIAS && (HARDONLY || (FULL && LOG2N >= SDR_FULL_IDX_ALIAS_FROM));
+    static constexpr int IDX_RAW_BYTES = HARD_PATH ? N * SPW * static_cast<int>(sizeof(idx_t)) : 0;
+    static constexpr int IDX_BYTES = IDX_ALIAS ? 0 : IDX_RAW_BYTES;
+    // ... and park the reference bits there as well, written behind the last exchange read instead of ahead of the transform
+    // (one more barrier): N = 8192 with 64-QAM and up would miss the second workgroup by 0.6 to 4.6 KiB otherwise.
+    static constexpr bool REF_ALIAS = FULL && DEMAP && IDX_ALIAS;
     static constexpr int REF_SYM_BYTES = N * (DEMAP ? BPS : 8) / 8;      // reference bits of one symbol
-    static constexpr int REF_BYTES = (FULL && DEMAP) ? REF_SYM_BYTES * SPW : 0;
+    static constexpr int REF_RAW_BYTES = (FULL && DEMAP) ? REF_SYM_BYTES * SPW : 0;
+    static constexpr int REF_BYTES = REF_ALIAS ? 0 : REF_RAW_BYTES;
     static constexpr int CHUNK = O::kGroupOut * BPS;                     // LLR floats per lane per output block
     // Several symbols per wave (N <= 256): one output block is a run of TPS * CHUNK floats per symbol.  Where that
     // run is not a whole number of 128-byte lines (N = 64 at QPSK / 64-QAM / 1024-QAM: 64 / 192 / 320 bytes) two
@@ -504,6 +525,10 @@ struct RxShape {
     static constexpr bool STG_ALIAS = STAGE && STG_BYTES <= SYM_BYTES * SPW && (O::kWG == 64 || LOG2N >= SDR_ALIAS_FROM || FULL || GROUP > 1);
 #endif
     static_assert(GROUP == 1 || !STAGE || STG_ALIAS, "grouped symbols stage their LLRs inside their own exchange region");
+    static constexpr int IDX_OFF = IDX_ALIAS ? (STG_ALIAS ? (STG_BYTES + 15) & ~15 : 0) : DATA_BYTES + TW_BYTES;
+    static constexpr int REF_OFF = REF_ALIAS ? (IDX_OFF + IDX_RAW_BYTES + 15) & ~15 : DATA_BYTES + TW_BYTES + IDX_BYTES;
+    static_assert(!IDX_ALIAS || IDX_OFF + IDX_RAW_BYTES <= DATA_BYTES, "aliased hard decisions fit the exchange region");
+    static_assert(!REF_ALIAS || REF_OFF + REF_RAW_BYTES <= DATA_BYTES, "aliased reference bits fit the exchange region");
     static constexpr int STG_OFF = STG_ALIAS ? 0 : (DATA_BYTES + TW_BYTES + IDX_BYTES + REF_BYTES + 15) & ~15;
     // shared taps (8 bytes) and weights (4 bytes) of one set, GROUP > 1 only
     static constexpr int TAPS_OFF = (DATA_BYTES + TW_BYTES + IDX_BYTES + REF_BYTES + 15) & ~15;
@@ -542,12 +567,13 @@ struct RxShape {
     //   1  straight-line, one symbol group per workgroup, taps requested unconditionally behind the samples
     //   2  straight-line, taps requested per symbol ahead of the first exchange barrier (LATE_TAPS)
     //   3  straight-line, taps read in the epilogue where they are used (EPILOGUE_TAPS; N = 8192)
+    //   4  straight-line, taps requested per symbol behind the last exchange read (LATE_TAPS with LATE_AT 2; N = 8192)
     static constexpr int eq_form()
     {
 #ifdef SDR_EQ_FORM_ALL      // experiment: one form everywhere
         return SDR_EQ_FORM_ALL;
 #endif
-        if (BPS == 1) return LOG2N == 13 ? 3 : SDR_EQ_FORM_BPSK;
+        if (BPS == 1) return LOG2N == 13 ? SDR_EQ_FORM_13 : SDR_EQ_FORM_BPSK;
         switch (LOG2N) {
             case 6: return BPS == 2 ? 0 : 1;
             case 7: return BPS == 10 ? 0 : 1;
@@ -555,7 +581,7 @@ struct RxShape {
             case 10: return (BPS == 2 || BPS == 10) ? 0 : 1;
             case 11: return (BPS == 2 || BPS == 10) ? 0 : BPS == 4 ? 1 : 2;
             case 12: return BPS <= 4 ? 0 : BPS == 10 ? SDR_EQ_FORM_12_10 : 2;      // 1024-QAM: the run of two again since the unpacked build (-2.2 with the straight form)
-            case 13: return 3;
+            case 13: return SDR_EQ_FORM_13;
             default: return 0;      // N = 512: the run of two
         }
     }
@@ -565,7 +591,7 @@ struct RxShape {
     // point of the run of two; against round 2's straight form it wins at N = 2048 (64-QAM up) and 4096
     // (profiles/r2_eq_straight_line_ab.txt) and is what those shapes use.  Four waves per SIMD spill (-15 points).
     static constexpr bool LATE_TAPS = EQ && DEMAP && O::kPasses == 3 && (FULL ? SDR_LATE_TAPS_FULL
-                                              : SDR_LATE_TAPS < 0 ? (eq_form() == 2 || (SDR_LATE_13 && LOG2N == 13))      // same-box A/B against the straight form: +0.6 to +1.4 points (2048/16-QAM: -0.7)
+                                              : SDR_LATE_TAPS < 0 ? (eq_form() == 2 || eq_form() == 4 || (SDR_LATE_13 && LOG2N == 13))      // same-box A/B against the straight form: +0.6 to +1.4 points (2048/16-QAM: -0.7)
                                                                   : (SDR_LATE_TAPS && LOG2N >= SDR_LATE_FROM && LOG2N <= 12));
     // Only the tap-holding instantiations take a run of symbol groups per workgroup (taps reloaded
     // once per run).  The others take exactly one group and are straight-line code: nothing is
@@ -597,6 +623,7 @@ struct RxShape {
     }
     static constexpr bool EQ_STRAIGHT_RULE = FULL ? full_straight() : (eq_form() == 1);
 #endif
+    static constexpr int LATE_AT = (eq_form() == 4) ? SDR_LATE_AT_13 : SDR_LATE_AT;
     // N = 8192 (E = 32): 96 tap registers beside 64 of data and the last pass's twiddles do not fit 256
     // (one wave per SIMD, or spills with late taps); there the epilogue reads each register group's taps
     // and weights right where it uses them and leaves the hoisting to the compiler.
@@ -632,7 +659,7 @@ struct RxShape {
 #ifndef SDR_HARD_WPE
 #define SDR_HARD_WPE 1
 #endif
-    static constexpr int MIN_WAVES = GROUP > 1 ? 1 : (HARDONLY && LOG2N <= 10) ? SDR_HARD_WPE : LOG2N >= 13 ? (LATE_TAPS ? SDR_LATE_13_WPE : EPILOGUE_TAPS ? 2 : (FULL || EQ || HARDONLY) ? 1 : 2) : FULL ? SDR_EQ_WPE : EQ ? (LATE_TAPS ? SDR_LATE_WPE : SDR_EQ_WPE) : 1;
+    static constexpr int MIN_WAVES = GROUP > 1 ? 1 : (HARDONLY && LOG2N <= 10) ? SDR_HARD_WPE : LOG2N >= 13 ? (LATE_TAPS ? SDR_LATE_13_WPE : EPILOGUE_TAPS ? 2 : (FULL && IDX_ALIAS) ? 2 : (FULL || EQ || HARDONLY) ? 1 : 2) : FULL ? SDR_EQ_WPE : EQ ? (LATE_TAPS ? SDR_LATE_WPE : SDR_EQ_WPE) : 1;
     static constexpr int even_share() { const int w = (LDS_WAVES + 3) / 4; return w < 1 ? 1 : w > 8 ? 8 : w; }
 #ifdef SDR_NO_MAX_WAVES
     static constexpr int MAX_WAVES = 8;
@@ -665,8 +692,8 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG * GROUP)
     constexpr bool LATE_TAPS = S::LATE_TAPS, LOOP = S::LOOP;
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
     unsigned char* lds_data = lds;
-    [[maybe_unused]] idx_t* lds_idx = reinterpret_cast<idx_t*>(S::IDX_ALIAS ? lds : lds + DATA_BYTES + TW_BYTES);
-    [[maybe_unused]] unsigned char* lds_ref = lds + DATA_BYTES + TW_BYTES + IDX_BYTES;
+    [[maybe_unused]] idx_t* lds_idx = reinterpret_cast<idx_t*>(lds + S::IDX_OFF);
+    [[maybe_unused]] unsigned char* lds_ref = lds + S::REF_OFF;
 
     // GROUP > 1: `tid` is the thread's id inside its symbol's kWG threads, `gslot` the symbol's place in the workgroup
     const int gslot = GROUP > 1 ? static_cast<int>(threadIdx.x) / O::kWG : 0;
@@ -858,24 +885,29 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG * GROUP)
             __syncthreads();
         }
         if constexpr (PREFETCH_TAPS && !LATE_TAPS && S::TAPS_AFTER) load_taps();      // straight-line: unconditional, behind the samples
-        if constexpr (FULL && DEMAP) {
+        auto park_ref = [&]() {
             static_for<REF_PER_THREAD>([&](auto R) {
                 constexpr int r = R;
                 int i = r * TPS + t;
                 if (i > REF_WORDS - 1) i = REF_WORDS - 1;          // duplicates store the same word
                 reinterpret_cast<uint32_t*>(lds_ref)[slot * REF_WORDS + i] = refw[r];
             });
-        }
+        };
+        if constexpr (FULL && DEMAP && !S::REF_ALIAS) park_ref();
 
         if constexpr (LATE_TAPS) {
             auto late = [&]() { load_taps(); };
-            fft_run<LOG2N, false, decltype(late), SDR_LATE_AT>(x, lds_data, addr, tw, std::move(late));
+            fft_run<LOG2N, false, decltype(late), S::LATE_AT>(x, lds_data, addr, tw, std::move(late));
         } else {
             fft_run<LOG2N, false, NoLateWork, 1, WAVE_SYNC>(x, lds_data, addr, tw);
         }
 
         // every wave is past its last exchange read (staging strips alias it); GROUP > 1: the shared taps are in LDS
         if constexpr ((STG_ALIAS || S::IDX_ALIAS) && O::kWG > 64) __syncthreads();
+        if constexpr (S::REF_ALIAS) {      // reference bits into the dead exchange region, visible to the symbol's other threads
+            park_ref();
+            if constexpr (O::kWG > 64) __syncthreads(); else symbol_sync<true>();
+        }
 
         // ---- epilogue: bins are in natural order, k = reg_pos(LAST, m) | pos_last ----
         constexpr int GO = O::kGroupOut;   // adjacent bins held in registers m = GO*h + (0..GO-1)
@@ -928,16 +960,41 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG * GROUP)
             }
         }
         if constexpr (DEMAP) {
+            // EPILOGUE_TAPS with SDR_EPI_AHEAD > 0: the taps of register group h + AHEAD are requested before group h
+            // is worked on (the run-time branches on p.eq / p.wgt and the staging barriers end the compiler's scheduling
+            // regions, so it hoists nothing across groups by itself: one exposed memory latency per group).
+            constexpr int NBLK = E / GO;
+            constexpr int AHEAD = S::EPILOGUE_TAPS ? (SDR_EPI_AHEAD < NBLK ? SDR_EPI_AHEAD : NBLK) : 0;
+            [[maybe_unused]] float2 epv[AHEAD > 0 ? E : 1];
+            [[maybe_unused]] float epw[AHEAD > 0 ? E : 1];
+            [[maybe_unused]] auto epi_load = [&]<int H_>() {
+                const float2* dummy = p.rx + static_cast<size_t>(sym) * in_stride;
+                const float2* eq_src = p.eq ? p.eq + tap_set * N : dummy;
+                const float* wgt_src = p.wgt ? p.wgt + tap_set * N : reinterpret_cast<const float*>(dummy);
+                const int k = O::reg_pos(LAST, H_ * GO) | pos_last;
+                if constexpr (GO == 2) {
+                    const float4 v = *reinterpret_cast<const float4*>(eq_src + k);
+                    const float2 u = *reinterpret_cast<const float2*>(wgt_src + k);
+                    epv[H_ * 2] = make_float2(v.x, v.y); epv[H_ * 2 + 1] = make_float2(v.z, v.w);
+                    epw[H_ * 2] = u.x; epw[H_ * 2 + 1] = u.y;
+                } else {
+                    static_for<GO>([&](auto G) { constexpr int g = G; epv[H_ * GO + g] = eq_src[k + g]; epw[H_ * GO + g] = wgt_src[k + g]; });
+                }
+            };
+            if constexpr (AHEAD > 0) static_for<AHEAD>([&](auto Hh) { constexpr int h = Hh; epi_load.template operator()<h>(); });
             static_for<E / GO>([&](auto Hh) {
                 constexpr int h = Hh;
                 const int k = O::reg_pos(LAST, h * GO) | pos_last;
                 float l[GO * BPS];
                 unsigned idx[GO];
+                if constexpr (AHEAD > 0 && h + AHEAD < NBLK) epi_load.template operator()<h + AHEAD>();
                 // EPILOGUE_TAPS: this register group's taps and weights, read unconditionally (dummy source when an
                 // array is missing) so that the compiler can count and hoist the loads
                 [[maybe_unused]] float2 epi_eq[GO];
                 [[maybe_unused]] float epi_w[GO];
-                if constexpr (S::EPILOGUE_TAPS) {
+                if constexpr (S::EPILOGUE_TAPS && AHEAD > 0) {
+                    static_for<GO>([&](auto G) { constexpr int g = G; epi_eq[g] = epv[h * GO + g]; epi_w[g] = epw[h * GO + g]; });
+                } else if constexpr (S::EPILOGUE_TAPS) {
                     const float2* dummy = p.rx + static_cast<size_t>(sym) * in_stride;
                     const float2* eq_src = p.eq ? p.eq + tap_set * N : dummy;
                     const float* wgt_src = p.wgt ? p.wgt + tap_set * N : reinterpret_cast<const float*>(dummy);
