@@ -473,12 +473,14 @@ struct RxShape {
 #ifndef SDR_HARD_IDX_ALIAS
 #define SDR_HARD_IDX_ALIAS 1
 #endif
-    // The every-output variants do the same from SDR_FULL_IDX_ALIAS_FROM on (behind the staging strips, which
-    // alias the region too): at N = 8192 it is the difference between one and two workgroups per CU.
+    // The every-output variants do the same from SDR_FULL_IDX_ALIAS_FROM on and at 1024-QAM (behind the staging strips,
+    // which alias the region too): at N = 8192 it is the difference between one and two workgroups per CU (+12.5 to
+    // +19.7 points), at N = 4096 +1.9 to +3.2, at 1024-QAM +1.5 to +3.3; the other shapes are level or lose the
+    // price of the extra barrier (-0.4 to -1.9; same-buffer A/Bs, tools/abbench.py).
 #ifndef SDR_FULL_IDX_ALIAS_FROM
-#define SDR_FULL_IDX_ALIAS_FROM 13
+#define SDR_FULL_IDX_ALIAS_FROM 12
 #endif
-    static constexpr bool IDX_ALIAS = HARD_PATH && SDR_HARD_IDX_ALIAS && (HARDONLY || (FULL && LOG2N >= SDR_FULL_IDX_ALIAS_FROM));
+    static constexpr bool IDX_ALIAS = HARD_PATH && SDR_HARD_IDX_ALIAS && (HARDONLY || (FULL && (LOG2N >= SDR_FULL_IDX_ALIAS_FROM || BPS == 10)));
     static constexpr int IDX_RAW_BYTES = HARD_PATH ? N * SPW * static_cast<int>(sizeof(idx_t)) : 0;
     static constexpr int IDX_BYTES = IDX_ALIAS ? 0 : IDX_RAW_BYTES;
     // ... and park the reference bits there as well, written behind the last exchange read instead of ahead of the transform
@@ -686,7 +688,7 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG * GROUP)
     constexpr int N = O::kN, E = O::kE, TPS = O::kTPS, SPW = O::kSPW, LAST = O::kLast;
     constexpr int BPS = S::BPS;
     constexpr bool DEMAP = S::DEMAP, HARD_PATH = S::HARD_PATH, STAGE = S::STAGE, STG_ALIAS = S::STG_ALIAS;
-    constexpr int SYM_BYTES = S::SYM_BYTES, DATA_BYTES = S::DATA_BYTES, TW_BYTES = S::TW_BYTES, IDX_BYTES = S::IDX_BYTES;
+    constexpr int SYM_BYTES = S::SYM_BYTES, DATA_BYTES = S::DATA_BYTES;
     constexpr int REF_SYM_BYTES = S::REF_SYM_BYTES, CHUNK = S::CHUNK, STG_STRIDE = S::STG_STRIDE;
     constexpr int STG_WAVE_BYTES = S::STG_WAVE_BYTES, STG_OFF = S::STG_OFF, LDS_BYTES = S::LDS_BYTES;
     constexpr bool LATE_TAPS = S::LATE_TAPS, LOOP = S::LOOP;
