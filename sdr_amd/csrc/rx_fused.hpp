@@ -644,6 +644,15 @@ struct RxShape {
 #endif
     static constexpr bool EQ_STRAIGHT = EQ && DEMAP && !LATE_TAPS && GROUP == 1 && EQ_STRAIGHT_RULE && !SDR_EQ_FORCE_LOOP;
     static constexpr bool TAPS_AFTER = EQ_STRAIGHT;
+    // Symbol groups per workgroup of the loop form (taps reloaded when the set changes, i.e. once per run inside a set).
+    // Seven, as a real loop, where the taps' way through L2 weighs most against the symbol's own bytes (same-buffer
+    // A/B against the run of two: N = 4096 BPSK +4.9, QPSK +4.2, 1024-QAM +1.3; N = 2048 +2.3 / +1.6 / +0.8);
+    // it loses 0.4 to 4.5 points at N <= 1024 and at 4096/16-QAM, and fourteen is no better than seven.
+#ifdef SDR_EQ_RUN
+    static constexpr int RUN = SDR_EQ_RUN;
+#else
+    static constexpr int RUN = ((LOG2N == 11 || LOG2N == 12) && (BPS <= 2 || BPS == 10)) ? 7 : 2;
+#endif
     static constexpr bool LOOP = EQ && !LATE_TAPS && !SDR_EQ_NOLOOP && GROUP == 1 && !EQ_STRAIGHT && !EPILOGUE_TAPS;
 
     // Waves per SIMD.  Lower bound = register budget: the tap-holding and FULL variants must not
@@ -1159,7 +1168,12 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG * GROUP)
         }
     };
     process(grp_begin);
-    if constexpr (LOOP) {
+    if constexpr (LOOP && S::RUN > 2) {
+        for (unsigned long long g = grp_begin + 1; g < grp_end; ++g) {      // uniform over the workgroup
+            __syncthreads();
+            process(g);
+        }
+    } else if constexpr (LOOP) {
         if (grp_begin + 1 < grp_end) {                 // uniform over the workgroup
             __syncthreads();                           // LDS regions are reused by the next symbol group
             process(grp_begin + 1);
@@ -1214,7 +1228,7 @@ int launch_rx_fused(sdr_ctx* ctx, const RxParams& p)
     // at N = 512 ... 4096, and far better than a resident grid striding over the batch; the
     // per-workgroup twiddle set-up is cheap, the finer grain balances better).  The tap-holding
     // variants take two, reloading their taps once per run (65 % against 61 %).
-    const unsigned long long per_wg = S::LOOP ? 2 : 1;
+    const unsigned long long per_wg = S::LOOP ? S::RUN : 1;
     if (tune.debug) {
         int nb = 0;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, S::WG_THREADS, static_cast<size_t>(tune.lds_pad > 0 ? tune.lds_pad : 0));

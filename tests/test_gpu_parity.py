@@ -411,14 +411,18 @@ def test_demod_llr_only_every_shape(ctx, oracle, n, bps):
     assert bool((guard[n_sym * n * bps:] == 7.5).all())
 
 
-@pytest.mark.parametrize("n,cp,bps", [(64, 16, 2), (256, 64, 4), (1024, 256, 4), (1024, 256, 6), (2048, 512, 6), (4096, 1024, 8), (512, 128, 2),
-                                      (128, 32, 6), (256, 64, 8), (64, 16, 6)])
+@pytest.mark.parametrize("n,cp,bps,per", [(64, 16, 2, 7), (256, 64, 4, 7), (1024, 256, 4, 7), (1024, 256, 6, 7), (2048, 512, 6, 7), (4096, 1024, 8, 7), (512, 128, 2, 7),
+                                          (128, 32, 6, 7), (256, 64, 8, 7), (64, 16, 6, 7),
+                                          # runs of seven symbols per workgroup, sets aligned with the runs and not
+                                          (4096, 1024, 2, 7), (4096, 1024, 1, 5), (2048, 512, 10, 14), (2048, 512, 2, 3), (4096, 1024, 10, 5), (2048, 512, 1, 14),
+                                          # taps requested four register groups ahead (N = 8192)
+                                          (8192, 2048, 1, 7), (8192, 2048, 2, 5), (8192, 2048, 8, 14)])
 @pytest.mark.parametrize("which", ["both", "taps", "weights"])
-def test_demod_llr_only_with_taps_or_weights(ctx, oracle, n, cp, bps, which):
+def test_demod_llr_only_with_taps_or_weights(ctx, oracle, n, cp, bps, per, which):
     """LLR-only output takes the tap-prefetching instantiation; either array may be absent."""
     from sdr_amd.link import noise_sigma
     rng = np.random.default_rng(n + bps)
-    n_sym, per = 31, 7
+    n_sym = 31 if n <= 4096 else 17
     n_sets = (n_sym + per - 1) // per
     h = (rand_c(rng, (n_sets, n)) * np.float32(np.sqrt(0.5))).astype(np.complex64)
     h[np.abs(h) < 0.1] += np.float32(0.3)
