@@ -568,7 +568,7 @@ struct RxShape {
     //   0  run of two symbols, taps held in registers and requested ahead of the samples when the set changes
     //   1  straight-line, one symbol group per workgroup, taps requested unconditionally behind the samples
     //   2  straight-line, taps requested per symbol ahead of the first exchange barrier (LATE_TAPS)
-    //   3  straight-line, taps read in the epilogue where they are used (EPILOGUE_TAPS; N = 8192)
+    //   3  straight-line, taps read in the epilogue SDR_EPI_AHEAD register groups ahead of their use (EPILOGUE_TAPS; N = 8192, 1024/1024-QAM)
     //   4  straight-line, taps requested per symbol behind the last exchange read (LATE_TAPS with LATE_AT 2; N = 8192)
     static constexpr int eq_form()
     {
@@ -580,7 +580,7 @@ struct RxShape {
             case 6: return BPS == 2 ? 0 : 1;
             case 7: return BPS == 10 ? 0 : 1;
             case 8: return (BPS <= 4 || BPS == 10) ? 0 : 1;
-            case 10: return (BPS == 2 || BPS == 10) ? 0 : 1;
+            case 10: return BPS == 2 ? 0 : BPS == 10 ? 3 : 1;      // 1024-QAM: +3.2 with the epilogue form and its prefetch (the form loses 0.2 to 8.5 in every other cell below N = 8192)
             case 11: return (BPS == 2 || BPS == 10) ? 0 : BPS == 4 ? 1 : 2;
             case 12: return BPS <= 4 ? 0 : BPS == 10 ? SDR_EQ_FORM_12_10 : 2;      // 1024-QAM: the run of two again since the unpacked build (-2.2 with the straight form)
             case 13: return SDR_EQ_FORM_13;
@@ -632,7 +632,13 @@ struct RxShape {
 #ifndef SDR_EPILOGUE_TAPS_13
 #define SDR_EPILOGUE_TAPS_13 1      // same-box A/B: +0.2 to +9.5 points over one wave per SIMD with held taps (profiles/r2_eq_straight_line_ab.txt)
 #endif
-    static constexpr bool EPILOGUE_TAPS = EQ && DEMAP && !FULL && GROUP == 1 && eq_form() == 3 && SDR_EPILOGUE_TAPS_13;
+    // The every-output variants with taps take the same form from SDR_EPILOGUE_TAPS_FULL_FROM on and at 2048/1024-QAM:
+    // held taps cost them 50 to 100 spilled registers at N = 8192 with two waves per SIMD (+3.4 to +14.8 points,
+    // same-buffer A/B); N = 4096: +2.5 to +6.7; 2048/1024-QAM: +5.2 (the other 2048 shapes: -0.6 ... 0.0).
+#ifndef SDR_EPILOGUE_TAPS_FULL_FROM
+#define SDR_EPILOGUE_TAPS_FULL_FROM 12
+#endif
+    static constexpr bool EPILOGUE_TAPS = EQ && DEMAP && GROUP == 1 && SDR_EPILOGUE_TAPS_13 && (FULL ? (LOG2N >= SDR_EPILOGUE_TAPS_FULL_FROM || (LOG2N == 11 && BPS == 10)) : eq_form() == 3);
     // Non-temporal sample loads in the tap-reading variants: the samples are read once, the taps of a set
     // by up to 14 workgroups.  Same-buffer A/B (tools/abbench.py): +0.4 to +2.5 points at N = 1024, +0.9 to
     // +11.3 at N = 8192 (64-QAM: 47.7 -> 59.0 %), level (-0.5 ... +0.2) at the other sizes, which keep plain

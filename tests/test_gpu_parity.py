@@ -313,7 +313,7 @@ def test_demod_parity(ctx, oracle, n, cp, bps):
     assert same(counters.cpu().numpy(), 2 * c)
 
 
-@pytest.mark.parametrize("n,cp,bps", [(64, 16, 2), (1024, 256, 4), (2048, 512, 6), (4096, 1024, 8), (8192, 2048, 6)])
+@pytest.mark.parametrize("n,cp,bps", [(64, 16, 2), (1024, 256, 4), (2048, 512, 6), (4096, 1024, 8), (8192, 2048, 6), (2048, 512, 10), (4096, 1024, 2), (8192, 2048, 1)])
 def test_demod_with_equaliser_sets(ctx, oracle, n, cp, bps):
     from sdr_amd.link import noise_sigma
     rng = np.random.default_rng(n)
@@ -416,7 +416,7 @@ def test_demod_llr_only_every_shape(ctx, oracle, n, bps):
                                           # runs of seven symbols per workgroup, sets aligned with the runs and not
                                           (4096, 1024, 2, 7), (4096, 1024, 1, 5), (2048, 512, 10, 14), (2048, 512, 2, 3), (4096, 1024, 10, 5), (2048, 512, 1, 14),
                                           # taps requested four register groups ahead (N = 8192)
-                                          (8192, 2048, 1, 7), (8192, 2048, 2, 5), (8192, 2048, 8, 14)])
+                                          (8192, 2048, 1, 7), (8192, 2048, 2, 5), (8192, 2048, 8, 14), (1024, 256, 10, 14)])
 @pytest.mark.parametrize("which", ["both", "taps", "weights"])
 def test_demod_llr_only_with_taps_or_weights(ctx, oracle, n, cp, bps, per, which):
     """LLR-only output takes the tap-prefetching instantiation; either array may be absent."""
