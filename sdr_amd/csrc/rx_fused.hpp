@@ -632,13 +632,13 @@ struct RxShape {
 #ifndef SDR_EPILOGUE_TAPS_13
 #define SDR_EPILOGUE_TAPS_13 1      // same-box A/B: +0.2 to +9.5 points over one wave per SIMD with held taps (profiles/r2_eq_straight_line_ab.txt)
 #endif
-    // The every-output variants with taps take the same form from SDR_EPILOGUE_TAPS_FULL_FROM on and at 2048/1024-QAM:
+    // The every-output variants with taps take the same form from SDR_EPILOGUE_TAPS_FULL_FROM on, at N = 1024 and at 1024-QAM:
     // held taps cost them 50 to 100 spilled registers at N = 8192 with two waves per SIMD (+3.4 to +14.8 points,
-    // same-buffer A/B); N = 4096: +2.5 to +6.7; 2048/1024-QAM: +5.2 (the other 2048 shapes: -0.6 ... 0.0).
+    // same-buffer A/B); N = 4096: +2.5 to +6.7; 1024-QAM: -0.1 to +5.2; N = 1024: +0.6 to +4.9; the other shapes: -1.7 to +1.1, left alone.
 #ifndef SDR_EPILOGUE_TAPS_FULL_FROM
 #define SDR_EPILOGUE_TAPS_FULL_FROM 12
 #endif
-    static constexpr bool EPILOGUE_TAPS = EQ && DEMAP && GROUP == 1 && SDR_EPILOGUE_TAPS_13 && (FULL ? (LOG2N >= SDR_EPILOGUE_TAPS_FULL_FROM || (LOG2N == 11 && BPS == 10)) : eq_form() == 3);
+    static constexpr bool EPILOGUE_TAPS = EQ && DEMAP && GROUP == 1 && SDR_EPILOGUE_TAPS_13 && (FULL ? (LOG2N >= SDR_EPILOGUE_TAPS_FULL_FROM || BPS == 10 || LOG2N == 10) : eq_form() == 3);
     // Non-temporal sample loads in the tap-reading variants: the samples are read once, the taps of a set
     // by up to 14 workgroups.  Same-buffer A/B (tools/abbench.py): +0.4 to +2.5 points at N = 1024, +0.9 to
     // +11.3 at N = 8192 (64-QAM: 47.7 -> 59.0 %), level (-0.5 ... +0.2) at the other sizes, which keep plain
