@@ -93,10 +93,22 @@ __global__ void to_constl_kernel(const uint8_t* __restrict__ bytes, size_t n_sym
 }
 
 template <typename T, int MI, int MQ>
-__global__ void nearest_kernel(const T* __restrict__ sym, size_t n_sym, T inorm, uint16_t* __restrict__ index)
+__global__ void nearest_kernel(const T* __restrict__ sym, size_t n_sym, T inorm, uint16_t* __restrict__ index, bool pair_ok)
 {
+    typedef T vec2 __attribute__((ext_vector_type(2)));
     const ItemRange range = xcd_item_range(n_sym);
-    for (size_t k = range.first; k < range.last; k += range.step)
+    size_t k = range.first;
+    if (pair_ok) {
+        // four symbols per lane requested together: one load per trip leaves a wave one memory latency per symbol
+        for (; k + 3 * range.step < range.last; k += 4 * range.step) {
+            vec2 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const vec2*>(sym + 2 * (k + j * range.step));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) index[k + j * range.step] = static_cast<uint16_t>(demap_point<T, MI, MQ, false, true>(v[j].x, v[j].y, inorm, T(0), nullptr));
+        }
+    }
+    for (; k < range.last; k += range.step)
         index[k] = static_cast<uint16_t>(demap_point<T, MI, MQ, false, true>(sym[2 * k], sym[2 * k + 1], inorm, T(0), nullptr));
 }
 
@@ -122,9 +134,10 @@ __global__ void pack_kernel(const uint16_t* __restrict__ index, size_t n_sym, in
 // stream.  Nothing but the symbols is read and nothing but the bytes written (the two-kernel
 // form went through a 2-byte index array in HBM).
 template <typename T, int MI, int MQ>
-__global__ void __launch_bounds__(256) from_constl_kernel(const T* __restrict__ sym, size_t n_sym, T inorm, size_t n_bytes, uint8_t* __restrict__ out)
+__global__ void __launch_bounds__(256) from_constl_kernel(const T* __restrict__ sym, size_t n_sym, T inorm, size_t n_bytes, uint8_t* __restrict__ out, bool pair_ok, bool words_ok)
 {
     constexpr int BPS = MI + MQ;
+    typedef T vec2 __attribute__((ext_vector_type(2)));
     __shared__ __attribute__((aligned(16))) uint16_t strip[4][512];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint16_t* mine = strip[wave];
@@ -133,14 +146,51 @@ __global__ void __launch_bounds__(256) from_constl_kernel(const T* __restrict__ 
     // write-heavy kernels above measured 4 % slower here
     for (size_t tile = static_cast<size_t>(blockIdx.x) * 4 + wave; tile < n_tiles; tile += static_cast<size_t>(gridDim.x) * 4) {
         const size_t k0 = tile * 512;
+        if (pair_ok && k0 + 512 <= n_sym) {
+            // whole tile: the eight loads are requested together, ahead of the decisions (under a per-symbol bounds
+            // check every load sits in a basic block of its own and the wave pays eight memory latencies per tile)
+            vec2 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const vec2*>(sym + 2 * (k0 + j * 64 + lane));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) mine[j * 64 + lane] = static_cast<uint16_t>(demap_point<T, MI, MQ, false, true>(v[j].x, v[j].y, inorm, T(0), nullptr));
+        } else
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const size_t k = k0 + j * 64 + lane;
             unsigned idx = 0;
-            if (k < n_sym) idx = demap_point<T, MI, MQ, false, true>(sym[2 * k], sym[2 * k + 1], inorm, T(0), nullptr);
+            if (k < n_sym) {
+                T re, im;
+                if (pair_ok) { const vec2 v = *reinterpret_cast<const vec2*>(sym + 2 * k); re = v.x; im = v.y; }      // one load per symbol
+                else { re = sym[2 * k]; im = sym[2 * k + 1]; }
+                idx = demap_point<T, MI, MQ, false, true>(re, im, inorm, T(0), nullptr);
+            }
             mine[j * 64 + lane] = static_cast<uint16_t>(idx);
         }
         __builtin_amdgcn_wave_barrier();     // one wave: its LDS operations complete in order
+        if (words_ok && k0 + 512 <= n_sym) {
+            // A whole tile = 64 * BPS bytes = 16 * BPS four-byte words of the MSB-first stream: lane j builds word j from
+            // the (at most CNT) symbols that overlap it, so that a store instruction writes 256 contiguous bytes.  (A lane
+            // storing the BPS bytes of its own eight symbols one by one costs BPS instructions of 64 single bytes BPS
+            // apart: more write requests than the kernel has read requests from 256-QAM up.)
+            constexpr int WORDS = 16 * BPS;
+            constexpr int CNT = (32 + BPS - 1) / BPS + 1;
+            static_assert(CNT * BPS <= 64, "the symbols overlapping one word fit 64 bits");
+            uint32_t* out32 = reinterpret_cast<uint32_t*>(out + k0 / 8 * BPS);
+#pragma unroll
+            for (int j0 = 0; j0 < WORDS; j0 += 64) {
+                const int j = j0 + lane;
+                if (j < WORDS) {
+                    const int s0 = (32 * j) / BPS, off = 32 * j - s0 * BPS;
+                    unsigned long long acc = 0;
+#pragma unroll
+                    for (int i = 0; i < CNT; ++i) acc = (acc << BPS) | mine[s0 + i < 512 ? s0 + i : 511];      // bits of symbols past the word are shifted out
+                    out32[j] = __builtin_bswap32(static_cast<uint32_t>(acc >> (CNT * BPS - off - 32)));
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            continue;
+        }
         unsigned long long lo = 0;           // bit stream of the group, MSB first: 8 * BPS <= 80 bits
         unsigned hi = 0;                     // bits above 64 (1024-QAM only)
 #pragma unroll
@@ -173,10 +223,21 @@ __global__ void __launch_bounds__(256) soft_demap_kernel(const float* __restrict
     const ItemRange range = xcd_item_range(n_sym);
     const int lane = threadIdx.x & 63;
     // wave-uniform trip count: first - lane is the wave's first item
+    // The next trip's symbol and weight are requested before this trip's LLRs are worked out (index clamped into the
+    // range, so the loads are unconditional): two loads in flight per wave instead of one exposed latency per trip.
+    struct In { float re, im, w; };
+    auto fetch = [&](size_t k0_) {
+        size_t k_ = k0_ + lane;
+        if (k_ >= range.last) k_ = range.last - 1;
+        return In{sym[2 * k_], sym[2 * k_ + 1], wgt ? wgt[k_] : w0};
+    };
+    In next = fetch(range.first - lane);
     for (size_t k0 = range.first - lane; k0 < range.last; k0 += range.step) {
         const size_t k = k0 + lane;
+        const In cur = next;
+        next = fetch(k0 + range.step < range.last ? k0 + range.step : k0);
         float l[BPS];
-        if (k < range.last) demap_point<float, MI, MQ, true, false>(sym[2 * k], sym[2 * k + 1], inorm, wgt ? wgt[k] : w0, l);
+        if (k < range.last) demap_point<float, MI, MQ, true, false>(cur.re, cur.im, inorm, cur.w, l);
         if constexpr (STAGED) {
             if (wide_ok) {
                 float* mine = strip[threadIdx.x >> 6];
@@ -313,9 +374,9 @@ static int launch_nearest(sdr_ctx* ctx, bool is_double, int mod, const void* d_s
     const unsigned grid = grid_for(ctx, n_sym);
     dispatch_mod(mod, [&]<int MI, int MQ>() {
         if (is_double)
-            hipLaunchKernelGGL((nearest_kernel<double, MI, MQ>), dim3(grid), dim3(kThreads), 0, ctx->stream, static_cast<const double*>(d_sym), n_sym, inorm_in<double>(mod), d_index);
+            hipLaunchKernelGGL((nearest_kernel<double, MI, MQ>), dim3(grid), dim3(kThreads), 0, ctx->stream, static_cast<const double*>(d_sym), n_sym, inorm_in<double>(mod), d_index, reinterpret_cast<uintptr_t>(d_sym) % (2 * sizeof(double)) == 0);
         else
-            hipLaunchKernelGGL((nearest_kernel<float, MI, MQ>), dim3(grid), dim3(kThreads), 0, ctx->stream, static_cast<const float*>(d_sym), n_sym, inorm_in<float>(mod), d_index);
+            hipLaunchKernelGGL((nearest_kernel<float, MI, MQ>), dim3(grid), dim3(kThreads), 0, ctx->stream, static_cast<const float*>(d_sym), n_sym, inorm_in<float>(mod), d_index, reinterpret_cast<uintptr_t>(d_sym) % (2 * sizeof(float)) == 0);
     });
     SDR_HIP(hipGetLastError());
     return SDR_OK;
@@ -339,9 +400,11 @@ int from_constl_dev(sdr_ctx* ctx, bool is_double, int mod, const void* d_sym, si
     static_assert(kThreads == 256, "from_constl_kernel is written for four waves per workgroup");
     dispatch_mod(mod, [&]<int MI, int MQ>() {
         if (is_double)
-            hipLaunchKernelGGL((from_constl_kernel<double, MI, MQ>), dim3(grid), dim3(kThreads), 0, ctx->stream, static_cast<const double*>(d_sym), n_sym, inorm_in<double>(mod), n_bytes, d_bytes);
+            hipLaunchKernelGGL((from_constl_kernel<double, MI, MQ>), dim3(grid), dim3(kThreads), 0, ctx->stream, static_cast<const double*>(d_sym), n_sym, inorm_in<double>(mod), n_bytes, d_bytes,
+                               reinterpret_cast<uintptr_t>(d_sym) % (2 * sizeof(double)) == 0, reinterpret_cast<uintptr_t>(d_bytes) % 4 == 0);
         else
-            hipLaunchKernelGGL((from_constl_kernel<float, MI, MQ>), dim3(grid), dim3(kThreads), 0, ctx->stream, static_cast<const float*>(d_sym), n_sym, inorm_in<float>(mod), n_bytes, d_bytes);
+            hipLaunchKernelGGL((from_constl_kernel<float, MI, MQ>), dim3(grid), dim3(kThreads), 0, ctx->stream, static_cast<const float*>(d_sym), n_sym, inorm_in<float>(mod), n_bytes, d_bytes,
+                               reinterpret_cast<uintptr_t>(d_sym) % (2 * sizeof(float)) == 0, reinterpret_cast<uintptr_t>(d_bytes) % 4 == 0);
     });
     SDR_HIP(hipGetLastError());
     return SDR_OK;
