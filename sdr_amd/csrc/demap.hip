@@ -67,13 +67,23 @@ __global__ void to_constl_kernel(const uint8_t* __restrict__ bytes, size_t n_sym
     typedef T vec4 __attribute__((ext_vector_type(4)));
     const size_t n_pairs = (n_sym + 1) / 2;
     const ItemRange range = xcd_item_range(n_pairs);
+    const size_t n_in = (n_sym * BPS + 7) / 8;      // bytes of the bit stream
     for (size_t pr = range.first; pr < range.last; pr += range.step) {
         T v[4] = {T(0), T(0), T(0), T(0)};
+        // The pair's 2 * BPS bits start at bit 2 * pr * BPS and lie inside a four-byte window that starts at that bit's
+        // byte ((pos & 7) + 2 * BPS <= 27): four unconditional byte loads (index clamped to the stream), all in flight
+        // together, instead of a data-dependent loop of one to three loads per symbol.
+        const size_t pos = 2 * pr * BPS;
+        const size_t b0 = pos >> 3;
+        unsigned window = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) window = (window << 8) | bytes[b0 + i < n_in ? b0 + i : n_in - 1];
+        const unsigned both = (window >> (32u - static_cast<unsigned>(pos & 7) - 2u * BPS)) & ((1u << (2 * BPS)) - 1u);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const size_t k = 2 * pr + h;
             if (k >= n_sym) break;
-            const unsigned idx = stream_bits(bytes, k * BPS, BPS);
+            const unsigned idx = (both >> ((1 - h) * BPS)) & ((1u << BPS) - 1u);
             const unsigned gi = idx >> MQ, gq = idx & ((1u << MQ) - 1u);
             // level = 2 * gray_decode(g) - (L - 1): a small integer, exact in T (the table entry)
             const T li = MI == 0 ? T(0) : static_cast<T>(2 * static_cast<int>(gray_to_binary(gi)) - ((1 << MI) - 1));
