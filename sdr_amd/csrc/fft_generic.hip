@@ -62,10 +62,18 @@ __global__ void __launch_bounds__(1024) fft_lds_kernel(const typename Vec2<T>::t
         const bool valid = seq < g.n_seq;                  // barriers below are reached by every thread
         if (valid) {
             const V* src = in + seq * g.in_stride + g.in_offset;
-            for (unsigned i = tid; i < n; i += tps) {
-                const unsigned r = log2n ? (__brev(i) >> (32u - log2n)) : 0u;
-                buf[r] = src[i];
+            // four loads requested together per trip (a thread usually owns exactly four points): one load, wait,
+            // LDS store per trip left a single request in flight per thread
+            const auto rev = [&](unsigned i_) { return log2n ? (__brev(i_) >> (32u - log2n)) : 0u; };
+            unsigned i = tid;
+            for (; i + 3u * tps < n; i += 4u * tps) {
+                const V v0 = src[i], v1 = src[i + tps], v2 = src[i + 2u * tps], v3 = src[i + 3u * tps];
+                buf[rev(i)] = v0;
+                buf[rev(i + tps)] = v1;
+                buf[rev(i + 2u * tps)] = v2;
+                buf[rev(i + 3u * tps)] = v3;
             }
+            for (; i < n; i += tps) buf[rev(i)] = src[i];
         }
         // Stages are taken two at a time: a thread holds the four positions that differ in bits c
         // and c+1 and runs the four literal radix-2 butterflies of both stages on them (same
