@@ -252,13 +252,39 @@ struct FftTwiddles {
     float2 last[O::kLastTwCount];
     const float2* mid;           // LDS
 
+    // The middle pass's table goes to LDS through registers, a fixed number of loads per thread requested together
+    // (index clamped: surplus threads repeat the last entry).  As a loop of load, wait, LDS store every workgroup began
+    // with two or more exposed memory latencies.  request() asks for everything, park() -- any time before the first
+    // exchange barrier, e.g. behind the request for the samples -- writes the LDS table.
+    static constexpr int MID_PER = O::kMidCount > 0 ? (O::kMidCount + O::kWG - 1) / O::kWG : 0;
+    float2 midv[MID_PER > 0 ? MID_PER : 1];
+
+    __device__ __forceinline__ void park(int tid)
+    {
+        static_for<MID_PER>([&](auto I) {
+            constexpr int k = I;
+            int i = tid + k * O::kWG;
+            if (i > O::kMidCount - 1) i = O::kMidCount - 1;
+            const_cast<float2*>(mid)[i] = midv[k];
+        });
+    }
+
     // fills the LDS table (callers __syncthreads() before the first run) and the registers
     __device__ __forceinline__ void init(const float2* __restrict__ tw, float2* lds_mid, int tid, const FftAddr<LOG2N>& a)
     {
+        request(tw, lds_mid, tid, a);
+        park(tid);
+    }
+
+    __device__ __forceinline__ void request(const float2* __restrict__ tw, float2* lds_mid, int tid, const FftAddr<LOG2N>& a)
+    {
         static_for<(1 << P::kR[0]) - 1>([&](auto I) { constexpr int i = I; first[i] = tw[i]; });
-        if constexpr (O::kMidCount > 0) {
-            for (int i = tid; i < O::kMidCount; i += O::kWG) lds_mid[i] = tw[O::kMidFirst + i];
-        }
+        static_for<MID_PER>([&](auto I) {
+            constexpr int k = I;
+            int i = tid + k * O::kWG;
+            if (i > O::kMidCount - 1) i = O::kMidCount - 1;
+            midv[k] = tw[O::kMidFirst + i];
+        });
         mid = lds_mid;
         constexpr int LAST = O::kLast;
         const int jt = a.pos_last & ((1 << P::kC0[LAST]) - 1);
@@ -417,6 +443,9 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 #endif
 #ifndef SDR_LATE_AT_13
 #define SDR_LATE_AT_13 2
+#endif
+#ifndef SDR_TW_PARK_LATE
+#define SDR_TW_PARK_LATE 0      // 1: the LDS twiddle table is written behind the request for the first symbol's samples -- same-buffer A/B: -1.8 to -6.1 points at N = 1024 ... 4096 (level elsewhere), so the set-up keeps its own wait
 #endif
 #ifndef SDR_EPI_AHEAD
 #define SDR_EPI_AHEAD 4      // same-buffer A/B at N = 8192: BPSK 32.4 -> 49.3 %, QPSK 42.7 -> 56.6, 16-QAM 50.3 -> 60.0, the others +0.2 to +1.0 (8: level, 1024-QAM -1.6)
@@ -724,7 +753,11 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG * GROUP)
     FftAddr<LOG2N> addr;
     addr.init(t, slot, SYM_BYTES);
     FftTwiddles<LOG2N> tw;
-    tw.init(p.tw, reinterpret_cast<float2*>(lds + DATA_BYTES), tid, addr);
+    // the middle pass's table: all of a thread's entries requested together, then written to LDS (one wait instead of a
+    // load-wait-store loop: level, -0.6 ... +0.9; writing it behind the request for the samples, SDR_TW_PARK_LATE, loses)
+    tw.request(p.tw, reinterpret_cast<float2*>(lds + DATA_BYTES), tid, addr);
+    [[maybe_unused]] bool tw_parked = !SDR_TW_PARK_LATE;
+    if constexpr (!SDR_TW_PARK_LATE) tw.park(tid);
     const int pos_last = addr.pos_last;
     const int in_thread = addr.in_thread;
 
@@ -732,7 +765,7 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG * GROUP)
 
     const unsigned long long n_groups = (p.n_sym + SPG - 1) / SPG;
     const size_t in_stride = static_cast<size_t>(N) + p.cp;
-    if constexpr (O::kMidCount > 0) __syncthreads();
+    if constexpr (O::kMidCount > 0 && !SDR_TW_PARK_LATE) __syncthreads();
 
     // global load of one symbol into registers: CP skipped, bit reversal folded into the index
     auto load_symbol = [&](unsigned long long grp_, float2 (&dst)[E]) {
@@ -891,6 +924,7 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG * GROUP)
 
         // ---- pass 0 ----
         load_symbol(grp, x);
+        if constexpr (SDR_TW_PARK_LATE) if (!tw_parked) { tw.park(tid); tw_parked = true; }
         if constexpr (GROUP > 1) {
             float4* lds_e = reinterpret_cast<float4*>(lds + S::TAPS_OFF);
             float4* lds_w = reinterpret_cast<float4*>(lds + S::TAPS_OFF + 8 * N);
