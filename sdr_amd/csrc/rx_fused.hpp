@@ -30,7 +30,10 @@
 // SDR_LATE_TAPS / SDR_LATE_TAPS_FULL / SDR_LATE_AT (taps per symbol instead of held), SDR_EQ_SET0,
 // SDR_NT_LOADS (non-temporal sample loads), SDR_PLAIN_STORES (LLR stores without the non-temporal
 // hint), SDR_NO_STAGE8 / SDR_NO_STG_ALIAS / SDR_ALIAS_FROM / SDR_NO_SMALL_STAGE (LLR staging
-// variants).  Run-time knobs: see RxTuning.
+// variants), SDR_EQ_FORM_ALL / SDR_EQ_FORM_13 / SDR_LATE_AT_13 / SDR_EPI_AHEAD / SDR_EQ_RUN / SDR_EPILOGUE_TAPS_FULL_FROM
+// (how and when the taps are fetched), SDR_FULL_IDX_ALIAS_FROM (hard decisions and reference bits in the exchange
+// region), SDR_STG_PAIRS / SDR_BINS_STAGED (line-sized stores at N = 64), SDR_TW_PARK_LATE (twiddle table set-up).
+// Run-time knobs: see RxTuning.
 #pragma once
 
 #include <hip/hip_runtime.h>
