@@ -528,6 +528,9 @@ struct RxShape {
 #ifndef SDR_STG_PAIRS
 #define SDR_STG_PAIRS 1
 #endif
+#ifndef SDR_STG_LINE4
+#define SDR_STG_LINE4 256
+#endif
 #ifndef SDR_STG_LINE
 #define SDR_STG_LINE 128      // bytes a staged run must be a multiple of
 #endif
@@ -539,7 +542,7 @@ struct RxShape {
     {
         if (!(SDR_STG_PAIRS && DEMAP && !HARDONLY && SPW > 1 && O::kWG == 64 && GROUP == 1 && stage_stride_bytes(CHUNK) == CHUNK * 4)) return 1;
         for (int nb = 1; nb <= 4; nb *= 2)
-            if ((nb * RUN_BYTES) % (CHUNK == 4 ? 256 : SDR_STG_LINE) == 0 && (O::kE / O::kGroupOut) % nb == 0) return nb;      // 16-QAM at N = 64 (one line per block, stored per lane): +3.9 staged in pairs; 256-byte runs are level or worse for the others
+            if ((nb * RUN_BYTES) % (CHUNK == 4 ? SDR_STG_LINE4 : SDR_STG_LINE) == 0 && (O::kE / O::kGroupOut) % nb == 0) return nb;      // 16-QAM at N = 64 (one line per block, stored per lane): +3.9 staged in pairs; 256-byte runs are level or worse for the others
         return 1;
     }
     static constexpr int STG_BLOCKS = stg_blocks();
