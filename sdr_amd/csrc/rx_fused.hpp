@@ -542,7 +542,7 @@ struct RxShape {
     {
         if (!(SDR_STG_PAIRS && DEMAP && !HARDONLY && SPW > 1 && O::kWG == 64 && GROUP == 1 && stage_stride_bytes(CHUNK) == CHUNK * 4)) return 1;
         for (int nb = 1; nb <= 4; nb *= 2)
-            if ((nb * RUN_BYTES) % (CHUNK == 4 ? SDR_STG_LINE4 : SDR_STG_LINE) == 0 && (O::kE / O::kGroupOut) % nb == 0) return nb;      // 16-QAM at N = 64 (one line per block, stored per lane): +3.9 staged in pairs; 256-byte runs are level or worse for the others
+            if ((nb * RUN_BYTES) % ((CHUNK == 4 || (LOG2N == 8 && (BPS == 2 || BPS == 10))) ? SDR_STG_LINE4 : SDR_STG_LINE) == 0 && (O::kE / O::kGroupOut) % nb == 0) return nb;      // 16-QAM at N = 64 (one line per block, stored per lane): +3.9 staged in pairs; N = 256 QPSK / 1024-QAM: +1.8 / +2.2 (with taps +2.3); 256-byte runs are level or worse for the others
         return 1;
     }
     static constexpr int STG_BLOCKS = stg_blocks();
