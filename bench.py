@@ -106,10 +106,21 @@ def cpu_baseline(n_fft, cp, bps, budget_s=12.0, threads=1):
             "sample": f"{done} symbols ({n_s}-symbol batch x {done // n_s} passes) of FFT-{n_fft}/{bps}-bit LLR+hard demod in {dt:.1f} s, {threads} thread(s) of {os.cpu_count()} host CPUs"}
 
 
-def time_workload(ctx, torch, dist, name, steps, warmup, world, rank, n_sym_override=None):
+def launch_stats(launch_ms, bytes_per_launch):
+    """Per-launch spread of one timed region (HIP events between consecutive launches): placement and box effects
+    move a kernel by a few points, so the average is reported with its minimum, median and maximum."""
+    v = sorted(launch_ms)
+    med = v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
+    frac = lambda ms: bytes_per_launch / (ms / 1e3) / 1e9 / HBM_PEAK_GBS
+    return {"launches": len(v), "ms_min": v[0], "ms_median": med, "ms_max": v[-1], "ms_avg": sum(v) / len(v),
+            "hbm_frac_best": frac(v[0]), "hbm_frac_median": frac(med), "hbm_frac_worst": frac(v[-1])}
+
+
+def time_workload(ctx, torch, group, name, steps, warmup, n_sym_override=None):
     n_fft, cp, bps, n_sym, ebn0, with_eq = WORKLOADS[name]
     if n_sym_override:
         n_sym = n_sym_override
+    world, rank = group.world, group.rank
     first = rank * ((n_sym + 13) // 14) * 14      # whole frames per rank, disjoint global symbol ranges
     rx, eq, wgt, w0, per = make_inputs(ctx, torch, n_fft, cp, bps, n_sym, ebn0, with_eq, seed=2, first_symbol=first)
     llr = torch.zeros((n_sym, n_fft, bps), dtype=torch.float32, device="cuda")
@@ -120,8 +131,7 @@ def time_workload(ctx, torch, dist, name, steps, warmup, world, rank, n_sym_over
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    group.barrier()
     torch.cuda.synchronize()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     t0 = time.perf_counter()
@@ -130,14 +140,9 @@ def time_workload(ctx, torch, dist, name, steps, warmup, world, rank, n_sym_over
         step()
         ev[i + 1].record()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    group.barrier()
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=("cuda" if dist.get_backend() == "nccl" else "cpu"))
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = group.max_over_ranks(time.perf_counter() - t0)
     # the memory system's rate for this traffic shape: same bytes, same access pattern, no arithmetic
     copy_gbs = None
     if eq is None:
@@ -164,14 +169,102 @@ def time_workload(ctx, torch, dist, name, steps, warmup, world, rank, n_sym_over
         "tap_bytes_per_symbol": tap_bytes_sym, "frac_incl_taps": (b_sym + tap_bytes_sym) * n_sym / avg_launch_s / 1e9 / HBM_PEAK_GBS,
         "sym_per_s": world * n_sym * steps / elapsed,
         "copy_shape_gbs": copy_gbs,
+        "per_launch": launch_stats(launch_ms, b_sym * n_sym),
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "traffic_unit": f"bytes per launch (rocprofv3 PMC, separate passes; profiles/{traffic_file})",
+                     "traffic": traffic, "traffic_unit": f"bytes per launch (rocprofv3 PMC, separate passes of an earlier build of the same kernel; profiles/{traffic_file})",
                      "algorithmic_bytes_per_launch": b_sym * n_sym, "bytes_per_symbol": b_sym, "symbols_per_launch": n_sym, "avg_launch_ms": avg_launch_s * 1e3},
     }
     res["buffers"] = {k: hex(v.data_ptr()) for k, v in (("rx", rx), ("llr", llr), ("eq", eq), ("wgt", wgt)) if v is not None}      # placement, for the record
     del rx, llr, eq, wgt
     torch.cuda.empty_cache()
     return res
+
+
+def time_demod_at_stated_size(ctx, torch, name, passes=2):
+    """BASELINE.json configs[2] at its STATED size, demodulator alone: all 4 Mi symbols (86 GB of samples) and their
+    taps and weights (7.4 GB) are generated once, untimed, and stay resident; the timed region is the equalised LLR
+    kernel over every chunk of symbols, each launch writing the one 12.9 GB LLR buffer (206 GB of LLRs do not fit
+    beside the samples).  Nothing but the demodulator runs inside the timed region."""
+    from sdr_amd.link import noise_sigma
+    c = dict(CHAIN[name])
+    n_fft, cp, bps, per, n_sym, chunk = c["n_fft"], c["cp"], c["bps"], c["per"], c["n_sym"], c["chunk"]
+    sigma = noise_sigma(n_fft, bps, c["ebn0"])
+    inv_n0 = bps * 10 ** (c["ebn0"] / 10)
+    n_sets = (n_sym + per - 1) // per
+    rx = torch.empty((n_sym, n_fft + cp), dtype=torch.complex64, device="cuda")
+    taps = torch.empty((n_sets, n_fft), dtype=torch.complex64, device="cuda")
+    wgt = torch.empty((n_sets, n_fft), dtype=torch.float32, device="cuda")
+    gen_sets = 4096                                        # 57344 symbols per generator call
+    for s0 in range(0, n_sets, gen_sets):
+        ns = min(gen_sets, n_sets - s0)
+        chan = ctx.link_channel(n_fft, c["seed"], s0, ns)
+        t, w = ctx.zf_taps(chan.view(-1), bps, inv_n0)
+        taps[s0:s0 + ns] = t.view(ns, n_fft)
+        wgt[s0:s0 + ns] = w.view(ns, n_fft)
+        first = s0 * per
+        cnt = min(ns * per, n_sym - first)
+        ctx.link_generate(n_fft, cp, bps, c["seed"], first, cnt, sigma, chan=chan, sym_per_set=per, want_bits=False, out_rx=rx[first:first + cnt])
+    del chan, t, w
+    torch.cuda.synchronize()
+    llr = torch.zeros((chunk, n_fft, bps), dtype=torch.float32, device="cuda")
+    starts = list(range(0, n_sym, chunk))
+
+    def one_pass(events=None):
+        for i, s0 in enumerate(starts):
+            n = min(chunk, n_sym - s0)
+            ctx.demod(rx[s0:s0 + n], n_fft, cp, bps, eq=taps[s0 // per:], llr_weight=wgt[s0 // per:], sym_per_set=per, out_llr=llr[:n])
+            if events is not None:
+                events[i + 1].record()
+
+    one_pass()                                             # warm-up: first touch of the LLR buffer, tables
+    torch.cuda.synchronize()
+    b_sym = algorithmic_bytes_per_symbol(n_fft, bps)
+    ms, t0 = [], time.perf_counter()
+    for _ in range(passes):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(starts) + 1)]
+        ev[0].record()
+        one_pass(ev)
+        torch.cuda.synchronize()
+        ms.append([ev[i].elapsed_time(ev[i + 1]) for i in range(len(starts))])
+    wall = (time.perf_counter() - t0) / passes
+    full = [m for p in ms for i, m in enumerate(p) if min(chunk, n_sym - starts[i]) == chunk]      # full-size chunks
+    kernel_s = sum(sum(p) for p in ms) / passes / 1e3
+    res = {"symbols": n_sym, "chunk_symbols": chunk, "chunks": len(starts), "resident_GB": (rx.numel() * 8 + taps.numel() * 8 + wgt.numel() * 4 + llr.numel() * 4) / 1e9,
+           "seconds_per_pass": kernel_s, "wall_seconds_per_pass": wall, "sym_per_s": n_sym / kernel_s, "llr_gbit_per_s": n_sym / kernel_s * n_fft * bps / 1e9,
+           "achieved_GBs": b_sym * n_sym / kernel_s / 1e9, "hbm_frac": b_sym * n_sym / kernel_s / 1e9 / HBM_PEAK_GBS,
+           "hbm_frac_incl_tap_bytes": (b_sym + 12.0 * n_fft / per) * n_sym / kernel_s / 1e9 / HBM_PEAK_GBS,
+           "per_launch": launch_stats(full, b_sym * chunk),
+           "what": "equalised LLR kernel (taps + weights per 14-symbol frame) over all resident symbols, chunk by chunk into one reused LLR buffer; generation untimed"}
+    del rx, taps, wgt, llr
+    torch.cuda.empty_cache()
+    return res
+
+
+def time_sweep(ctx, torch, bits=1e10, repeat=3):
+    """BASELINE.json configs[4] on this GPU: the default 70-point Eb/N0 grid (QPSK ... 256-QAM, FFT-1024), 1e10 bits,
+    ONE sdr_link_sweep_c32 launch per sweep.  ber_sweep.py is the multi-GPU form with the all-reduce."""
+    import ber_sweep
+    from sdr_amd import link
+    mods = [2, 4, 6, 8]
+    pts = link.plan_sweep(mods, ber_sweep.default_grid(mods, 1.0), 1024, bits)
+    rows = link.rank_points(pts, 1024, 0, 1)
+    counters = torch.zeros((len(pts), 8), dtype=torch.int64, device="cuda")
+    ctx.link_sweep(1024, 256, 5, rows, counters, zero_counters=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(repeat):
+        ctx.link_sweep(1024, 256, 5, rows, counters, zero_counters=True)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / repeat
+    c = counters.cpu().tolist()
+    roofline, util = ber_sweep.valu_figures(pts, c, 1024, dt, 1)
+    total_bits = sum(r[1] for r in c)
+    worst = max(abs(r[0] / r[1] / link.theory_ber(p.mod_bits, p.ebn0_db) - 1.0) for p, r in zip(pts, c) if r[0] >= 1000)
+    return {"points": len(pts), "total_bits": total_bits, "seconds_per_sweep": dt, "bits_per_s": total_bits / dt,
+            "frames_per_s": sum(p.n_frames for p in pts) / dt, "symbols_per_s": sum(r[4] for r in c) / dt, "launches_per_sweep": 1,
+            "checksum_bit_errors": sum(r[0] for r in c), "largest_deviation_from_closed_form_ber": worst,
+            "roofline": roofline, "valu_issue_utilisation": util,
+            "what": "generate -> IFFT -> AWGN -> FFT -> demap -> count on the device, nothing but 70 x 8 counters in HBM"}
 
 
 CHAIN = {
@@ -225,59 +318,52 @@ def main():
     ap.add_argument("--chain", default="", choices=[""] + sorted(CHAIN), help="only run this chunked whole-link configuration and print its JSON")
     ap.add_argument("--symbols", type=int, default=0, help="override symbols per GPU (debug)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--no-extra", action="store_true", help="skip the extra 64-QAM headline measurement")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra measurements (other configurations, config 3 at 4 Mi symbols, the Eb/N0 sweep)")
+    ap.add_argument("--demod-4m", action="store_true", help="only run configs[2]'s demodulator at its stated 4 Mi symbols and print its JSON")
+    ap.add_argument("--sweep", action="store_true", help="only run the one-GPU Eb/N0 sweep (configs[4]) and print its JSON")
     args = ap.parse_args()
 
     import torch
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # SDR_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks (ranks share
-        # devices round-robin, barriers and the max-over-ranks go over gloo); the driver's runs use RCCL.
-        backend = os.environ.get("SDR_BENCH_BACKEND", "nccl")
-        if backend == "nccl":
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
-            local_rank = local_rank % torch.cuda.device_count()
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend, rank=rank, world_size=world)
-    else:
-        torch.cuda.set_device(0)
-        local_rank = 0
+    from sdr_amd.dist import Group
+    group = Group(torch)      # under torch.distributed.run: RCCL process group, also with one rank
+    world, rank, local_rank = group.world, group.rank, group.local_rank
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
 
     from sdr_amd.ops import Context
     ctx = Context(local_rank)
+    if args.demod_4m or args.sweep:
+        r = time_demod_at_stated_size(ctx, torch, "fft2048_64qam_eq_4M_chain") if args.demod_4m else time_sweep(ctx, torch)
+        if rank == 0:
+            print(json.dumps({"config": {"workload": "fft2048_64qam_eq_4M_demod" if args.demod_4m else "ebn0_sweep_1e10"}, **r}))
+        ctx.close()
+        group.close()
+        return
     if args.chain:
         r = time_chain(ctx, torch, args.chain, max(1, args.steps), max(1, min(args.warmup, 2)), args.symbols or None)
         if rank == 0:
             print(json.dumps({"metric": "whole faded link, OFDM symbols/s (generate + equalised demodulation to LLRs + counting, resident chunks)", "value": r["sym_per_s"],
                               "unit": "OFDM symbols/s", "n_gpus": 1, "config": {"workload": args.chain}, **r}))
         ctx.close()
+        group.close()
         return
-    main_res = time_workload(ctx, torch, dist, args.workload, args.steps, args.warmup, world, rank, args.symbols or None)
-    extra = {}
+    main_res = time_workload(ctx, torch, group, args.workload, args.steps, args.warmup, args.symbols or None)
+    extra = {"process_group": group.describe()}
     if world == 1 and not args.no_extra and args.workload == "fft1024_16qam_1M" and not args.symbols:
-        r = time_workload(ctx, torch, dist, "fft1024_64qam_1M", max(3, args.steps // 2), 5, 1, 0)
-        extra["fft1024_64qam_1M"] = {"sym_per_s": r["sym_per_s"], "llr_gbit_per_s": r["sym_per_s"] * r["n_fft"] * r["bps"] / 1e9,
-                                     "hbm_frac": r["roofline"]["frac"], "achieved_GBs": r["roofline"]["achieved"], "equaliser": False}
-        # the north_star target shape with the equaliser ACTIVE, and the other configurations of
-        # BASELINE.json's list, for the record (not bench lines)
-        for name in ("fft1024_64qam_eq", "fft2048_64qam_eq", "fft4096_256qam", "fft64_qpsk"):
-            r = time_workload(ctx, torch, dist, name, max(3, args.steps // 2), 5, 1, 0)
+        # the north_star target shape without and with the equaliser ACTIVE, and the other configurations of
+        # BASELINE.json's list, for the record (not bench lines); first launches on fresh buffers run 5-15 % slow,
+        # hence 10 untimed launches ahead of each timed region
+        for name in ("fft1024_64qam_1M", "fft1024_64qam_eq", "fft2048_64qam_eq", "fft4096_256qam", "fft64_qpsk"):
+            r = time_workload(ctx, torch, group, name, max(10, args.steps // 2), 10)
             extra[name] = {"sym_per_s": r["sym_per_s"], "llr_gbit_per_s": r["sym_per_s"] * r["n_fft"] * r["bps"] / 1e9,
                            "hbm_frac": r["roofline"]["frac"], "achieved_GBs": r["roofline"]["achieved"], "symbols": r["n_sym"],
-                           "equaliser": r["with_eq"], "hbm_traffic_bytes_per_launch": r["roofline"]["traffic"]}
+                           "equaliser": r["with_eq"], "hbm_traffic_bytes_per_launch": r["roofline"]["traffic"], "per_launch": r["per_launch"]}
             if r["with_eq"]:
                 extra[name]["hbm_frac_incl_tap_bytes"] = r["frac_incl_taps"]
                 extra[name]["tap_bytes_per_symbol"] = r["tap_bytes_per_symbol"]
-        extra["fft2048_64qam_eq_4M_chain"] = time_chain(ctx, torch, "fft2048_64qam_eq_4M_chain", 2, 1)      # configs[2] at its stated size
+        extra["fft2048_64qam_eq_4M_demod"] = time_demod_at_stated_size(ctx, torch, "fft2048_64qam_eq_4M_chain")      # configs[2] at its stated size: the demodulator alone
+        extra["fft2048_64qam_eq_4M_chain"] = time_chain(ctx, torch, "fft2048_64qam_eq_4M_chain", 2, 1)               # ... and generated + demodulated + counted
+        extra["ebn0_sweep_1e10"] = time_sweep(ctx, torch)                                                            # configs[4] on one GPU
     if main_res.get("copy_shape_gbs"):
         extra["copy_of_same_shape"] = {"achieved_GBs": main_res["copy_shape_gbs"], "kernel_over_copy": main_res["roofline"]["achieved"] / main_res["copy_shape_gbs"],
                                        "what": "sdr_diag_copy_shape_c32: the kernel's bytes and access pattern with no arithmetic, same buffers"}
@@ -308,14 +394,13 @@ def main():
                        "symbols_per_gpu": main_res["n_sym"], "sharding": f"independent symbol batches x{world}"},
             "llr_gbit_per_s": main_res["sym_per_s"] * n_fft * bps / 1e9,
             "roofline": main_res["roofline"],
+            "per_launch": main_res["per_launch"],
             "cpu_baseline": cpu,
             "extra": extra,
         }
         print(json.dumps(line))
     ctx.close()
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    group.close()
 
 
 if __name__ == "__main__":

@@ -166,16 +166,21 @@ int sdr_ofdm_demod_host_c32(sdr_ctx* ctx, const sdr_demod_args* host_args, size_
  * loops, harnesses that forbid allocation.  Same arguments, same results, but the device memory
  * the kernels need beyond inputs and outputs (the twiddle table and the 1024 x 8 counter slots,
  * which sdr_ofdm_demod_c32 allocates lazily in the context) comes from one static device array of
- * 192 KiB per GPU, resolved and filled once per device by sdr_create.  The call enqueues one
- * 64 KiB hipMemsetAsync (counting calls only), the receive kernel and the counter fold -- no
- * hipMalloc, hipFree or copy.  Limits: n_fft = 64 ... 8192, even cp, 16-byte aligned buffers (what
- * the tuned kernels take); anything else is SDR_ERR_UNSUPPORTED.  Every call on a GPU shares that
- * GPU's array: calls that overlap in time on ONE GPU (two contexts or streams) race on the slots. */
+ * 384 KiB per GPU (four counter-slot sets + the tables of n_fft = 64 ... 8192), resolved and filled
+ * once per device by the first sdr_create on it; a failure of that set-up is reported HERE, not by
+ * sdr_create.  The call enqueues one 64 KiB hipMemsetAsync (counting calls only), the receive
+ * kernel and the counter fold -- no hipMalloc, hipFree or copy.  Limits: n_fft = 64 ... 8192, even
+ * cp, 16-byte aligned buffers (what the tuned kernels take); anything else is
+ * SDR_ERR_UNSUPPORTED.  Each live context owns one of the four slot sets of its GPU (claimed by
+ * sdr_create, returned by sdr_destroy), so contexts do not race; a fifth live context on one GPU
+ * has none and its COUNTING calls are refused with SDR_ERR_UNSUPPORTED (the others work).  As for
+ * every entry point, one context must not be used from two threads at once. */
 int sdr_ofdm_demod_noalloc_c32(sdr_ctx* ctx, const sdr_demod_args* args);
 
 /* Equaliser taps and LLR weights from a channel estimate H (n values):
  *   p = |H|^2, G = conj(H)/p, w = norm^2 * p * inv_n0. */
 int sdr_zf_taps_c32(sdr_ctx* ctx, int mod, const void* d_chan, size_t n, float inv_n0, void* d_taps, float* d_weight);
+int sdr_zf_taps_host_c32(sdr_ctx* ctx, int mod, const void* h_chan, size_t n, float inv_n0, void* h_taps, float* h_weight);
 
 /* Soft demapping alone (X2) on equalised symbols already in memory. */
 int sdr_soft_demap_c32(sdr_ctx* ctx, int mod, const void* d_sym, size_t n_sym, const float* d_weight, float weight0, float* d_llr);
@@ -213,7 +218,8 @@ int sdr_link_ber_c32(sdr_ctx* ctx, const sdr_link_args* args);
  * level) points, each with the symbol range this rank handles, generated -> demodulated ->
  * counted on the device; row i of d_counters (n_points x 8 uint64, accumulated into) receives
  * point i.  Same results as one sdr_link_ber_c32 call per point.  `points` is HOST memory (copied
- * to the device by the call); points with n_sym = 0 are skipped.  Model of the loop:
+ * to the device by the call, unless it is the table of the context's previous sweep, whose device copy
+ * is reused); points with n_sym = 0 are skipped.  Model of the loop:
  * app/QFDemoWindow.cpp:201-224 (one symbol per tick there). */
 /* SDR_POINT_HARD_ONLY: count bit and subcarrier-symbol errors from hard decisions alone, the way the
  * reference's own receive chain works (ofdm::rx -> from_constl, lib/inc/ofdm.hpp:37-43 +
@@ -228,6 +234,9 @@ typedef struct sdr_sweep_point {
     uint64_t first_symbol;      /* global index of the first symbol of this point handled here */
     uint64_t n_sym;
 } sdr_sweep_point;
+/* SDR_SWEEP_ZERO_COUNTERS: the call clears the n_points x 8 counters on the context's stream ahead of the launch
+ * (one hipMemsetAsync) instead of accumulating into what they hold: a sweep is then ONE library call. */
+#define SDR_SWEEP_ZERO_COUNTERS 1u
 typedef struct sdr_sweep_args {
     uint32_t struct_size;       /* = sizeof(sdr_sweep_args) */
     uint32_t n_fft;
@@ -236,6 +245,8 @@ typedef struct sdr_sweep_args {
     uint64_t seed;
     const sdr_sweep_point* points;   /* host */
     uint64_t* d_counters;            /* device, n_points x 8 */
+    uint32_t flags;                  /* 0, or SDR_SWEEP_ZERO_COUNTERS */
+    uint32_t reserved;               /* 0 */
 } sdr_sweep_args;
 int sdr_link_sweep_c32(sdr_ctx* ctx, const sdr_sweep_args* args);
 
@@ -328,6 +339,9 @@ void sdr_pipe_destroy(sdr_pipe* pipe);
 
 /* Host-visible pieces of the generator, for tests. */
 int sdr_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+/* The tables of the Gaussian generator the kernels use: 32 pairs (r_i, L_i) of the logarithm's range reduction,
+ * then 256 pairs (sin, cos)(2 pi j / 256); 576 floats written to host memory. */
+int sdr_rng_tables_f32(float* h_out);
 
 #ifdef __cplusplus
 }

@@ -8,7 +8,9 @@
 //   modulation::from_constl<Mod, T = double>(symbols, Mod = {})                      reference :96-112
 //   modulation::llr<Mod>(symbols, weight)            additive: max-log LLRs, fp32
 // Device failures (no GPU, HIP errors) cannot be returned through these value-returning
-// signatures; they throw std::runtime_error with the library's message.
+// signatures; to_constl / from_constl / llr throw std::runtime_error with the library's message.
+// e16QAM::nearest is noexcept like the reference's (:50): a device failure there prints the
+// library's message to stderr and calls std::terminate -- loud, never a silently wrong index.
 #pragma once
 
 #include <array>
@@ -17,6 +19,8 @@
 #include <concepts>
 #include <cstddef>
 #include <cstdint>
+#include <cstdio>
+#include <exception>
 #include <stdexcept>
 #include <string>
 #include <type_traits>
@@ -76,12 +80,22 @@ struct e16QAM : detail::square_qam<4> {
     template <typename T> static constexpr T norm = T(0x1.43d136248490fp-2);
     template <typename T> static constexpr T inorm = T(0x1.94c583ada5b53p+1);
     // nearest(): scale by inorm, ascending scan with strict '<' (reference :49-67), on the device
-    template <typename T> static std::uint8_t nearest(const std::complex<T>& pt)
+    template <typename T> static std::uint8_t nearest(const std::complex<T>& pt) noexcept
     {
         static_assert(std::is_same_v<T, float> || std::is_same_v<T, double>);
         std::uint16_t idx = 0;
-        if constexpr (std::is_same_v<T, float>) detail::check(sdr_nearest_host_c32(detail::context_or_throw(), 4, &pt, 1, &idx));
-        else detail::check(sdr_nearest_host_c64(detail::context_or_throw(), 4, &pt, 1, &idx));
+        std::string why;
+        sdr_ctx* ctx = sdrlib::thread_context::get(why);
+        int rc = SDR_ERR_HIP;
+        if (ctx) {
+            if constexpr (std::is_same_v<T, float>) rc = sdr_nearest_host_c32(ctx, 4, &pt, 1, &idx);
+            else rc = sdr_nearest_host_c64(ctx, 4, &pt, 1, &idx);
+            if (rc != SDR_OK) why = sdr_last_error();
+        }
+        if (rc != SDR_OK) {
+            std::fprintf(stderr, "sdrlib: e16QAM::nearest cannot reach the device: %s\n", why.c_str());
+            std::terminate();
+        }
         return static_cast<std::uint8_t>(idx);
     }
 };

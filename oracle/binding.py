@@ -177,6 +177,30 @@ def philox(ctr, key):
     return o
 
 
+def ln_unit(x):
+    return float(lib().orc_ln_unit(c_float(float(x))))
+
+
+def sincos_turn(k24):
+    o = np.zeros(2, dtype=np.float32)
+    lib().orc_sincos_turn(c_uint32(int(k24)), _p(o))
+    return float(o[0]), float(o[1])
+
+
+def gaussian_pair(x1, x2, sigma=1.0):
+    """Box-Muller pair of the generator from two 32-bit Philox words: (re, im)."""
+    o = np.zeros(2, dtype=np.float32)
+    lib().orc_gaussian_pair(c_uint32(int(x1)), c_uint32(int(x2)), c_float(float(sigma)), _p(o))
+    return float(o[0]), float(o[1])
+
+
+def rng_tables():
+    """The generator's tables: 32 (r_i, L_i) pairs, then 256 (sin, cos) pairs; 576 floats."""
+    o = np.zeros(576, dtype=np.float32)
+    lib().orc_rng_tables(_p(o))
+    return o
+
+
 def link_generate(n_fft, cp, bps, seed, g0, n_sym, sigma, chan=None, sym_per_set=0):
     rx = np.zeros((n_sym, n_fft + cp), dtype=np.complex64)
     bits = np.zeros(n_sym * n_fft * bps // 8, dtype=np.uint8)

@@ -354,65 +354,70 @@ inline unsigned tx_index(std::uint64_t seed, std::uint64_t g, std::uint32_t k, s
 }
 
 // Own elementary functions so that CPU and GPU produce identical bits: only +,-,* on floats,
-// integer bit manipulation, and one correctly rounded sqrt.
-inline float ln_unit(float x)   // x in [2^-24, 1], normal
+// integer bit manipulation, one correctly rounded sqrt and two small tables that both sides build with
+// the same double-precision formulas (round 3: table-based range reduction, about a third of the
+// operations of the long polynomials of rounds 1-2).
+//   ln table, 32 entries: interval i of the mantissa m in [1,2) has centre c_i = 1 + (i + 1/2)/32;
+//     entry = (r_i, L_i), r_i = fl(1/c_i), L_i = fl(-ln r_i); then ln m = L_i + log1p(f), f = m r_i - 1, |f| < 1/63
+//   sin/cos table, 256 entries: (sin, cos)(2 pi j / 256); the angle 2 pi k / 2^24 is j / 256 of a turn plus b, |b| <= pi/256
+struct RngTables {
+    float ln_r[32], ln_l[32], sn[256], cs[256];
+    RngTables()
+    {
+        for (int i = 0; i < 32; ++i) {
+            const double c = 1.0 + (static_cast<double>(i) + 0.5) / 32.0;
+            ln_r[i] = static_cast<float>(1.0 / c);
+            ln_l[i] = static_cast<float>(-std::log(static_cast<double>(ln_r[i])));
+        }
+        for (int j = 0; j < 256; ++j) {
+            const double a = 2.0 * 3.14159265358979323846264338327950288 * static_cast<double>(j) / 256.0;
+            sn[j] = static_cast<float>(std::sin(a));
+            cs[j] = static_cast<float>(std::cos(a));
+        }
+    }
+};
+inline const RngTables& rng_tables() { static const RngTables t; return t; }
+
+inline float ln_unit(float x)   // x in [2^-32, 1], normal
 {
+    const RngTables& tab = rng_tables();
     std::uint32_t bits;
     std::memcpy(&bits, &x, 4);
-    int e = static_cast<int>(bits >> 23) - 127;
-    std::uint32_t mb = (bits & 0x007FFFFFu) | 0x3F800000u;
+    const int e = static_cast<int>(bits >> 23) - 127;
+    const std::uint32_t idx = (bits >> 18) & 31u;
+    const std::uint32_t mb = (bits & 0x007FFFFFu) | 0x3F800000u;
     float m;
     std::memcpy(&m, &mb, 4);                    // [1,2)
-    if (m > 1.41421356f) { m = m * 0.5f; e += 1; }
-    const float f = m - 1.0f;
+    const float f = m * tab.ln_r[idx] - 1.0f;
+    const float q = f * 0.333333343f + -0.5f;
     const float z = f * f;
-    float p = 7.0376836292e-2f;
-    p = p * f + -1.1514610310e-1f;
-    p = p * f + 1.1676998740e-1f;
-    p = p * f + -1.2420140846e-1f;
-    p = p * f + 1.4249322787e-1f;
-    p = p * f + -1.6668057665e-1f;
-    p = p * f + 2.0000714765e-1f;
-    p = p * f + -2.4999993993e-1f;
-    p = p * f + 3.3333331174e-1f;
-    float y = (p * f) * z;
+    const float p = z * q + f;                  // log1p(f) = f - f^2/2 + f^3/3, |error| < 2e-8
     const float fe = static_cast<float>(e);
-    y = y + fe * -2.12194440e-4f;
-    y = y + z * -0.5f;
-    float r = f + y;
-    r = r + fe * 0.693359375f;
-    return r;
+    return (fe * 0.693147182f + tab.ln_l[idx]) + p;
 }
 
 inline void sincos_turn(std::uint32_t k24, float& s, float& c)   // angle = 2*pi*k24/2^24
 {
-    const std::uint32_t shifted = (k24 + 0x200000u) & 0xFFFFFFu;
-    const std::uint32_t quad = shifted >> 22;
-    const std::int32_t rem = static_cast<std::int32_t>(shifted & 0x3FFFFFu) - 0x200000;
-    const float th = (static_cast<float>(rem) * 2.384185791015625e-07f) * 1.57079637f;   // rem*2^-22*pi/2
-    const float z = th * th;
-    float ps = 2.75573192e-6f;
-    ps = ps * z + -1.98412698e-4f;
-    ps = ps * z + 8.33333333e-3f;
-    ps = ps * z + -1.66666667e-1f;
-    const float sn = th + (th * z) * ps;
-    float pc = 2.48015873e-5f;
-    pc = pc * z + -1.38888889e-3f;
-    pc = pc * z + 4.16666667e-2f;
-    pc = pc * z + -0.5f;
-    const float cs = 1.0f + z * pc;
-    switch (quad) {
-        case 0: s = sn;  c = cs;  break;
-        case 1: s = cs;  c = -sn; break;
-        case 2: s = -sn; c = -cs; break;
-        default: s = -cs; c = sn; break;
-    }
+    const RngTables& tab = rng_tables();
+    const std::uint32_t hi = (k24 + 0x8000u) >> 16;                          // nearest 256th of a turn, 0..256
+    const std::int32_t lo = static_cast<std::int32_t>(k24) - static_cast<std::int32_t>(hi << 16);   // -32768 .. 32767
+    const float b = static_cast<float>(lo) * 3.74507039e-7f;                 // 2 pi / 2^24
+    const float z = b * b;
+    const float sb = b + (b * z) * -0.166666672f;
+    const float cb = 1.0f + z * -0.5f;
+    const float sa = tab.sn[hi & 255u], ca = tab.cs[hi & 255u];
+    s = sa * cb + ca * sb;
+    c = ca * cb - sa * sb;
 }
 
+// Box-Muller on a 32-bit uniform u1 in [2^-32, 1] and a 24-bit angle: |z| <= sqrt(64 ln 2) sigma = 6.66 sigma
+// (a true Gaussian holds 2.7e-11 beyond that, per component).  Rounds 1-2 used 24 bits for u1 (5.77 sigma, 8e-9).
 inline void gaussian_pair(std::uint32_t x1, std::uint32_t x2, float sigma, float& re, float& im)
 {
-    const float u1 = static_cast<float>((x1 >> 8) + 1u) * 5.9604644775390625e-08f;   // (0,1]
-    const float rad = std::sqrt(-2.0f * ln_unit(u1));
+    const float u1 = (static_cast<float>(x1) + 1.0f) * 2.3283064365386963e-10f;   // (0,1]
+    float t = -2.0f * ln_unit(u1);
+    if (!(t > 0.0f)) t = 0.0f;                   // u1 = 1: the table form of ln may come out a few 1e-9 above 0
+    const float rad = std::sqrt(t);
     float s, c;
     sincos_turn(x2 >> 8, s, c);
     const float a = sigma * rad;
@@ -432,13 +437,16 @@ inline void payload_noise(std::uint64_t seed, std::uint64_t g, std::uint32_t n, 
     const std::uint32_t h = (n / half) & 1u;
     gaussian_pair(r[2 * h], r[2 * h + 1], sigma, re, im);
 }
-inline void cp_noise(std::uint64_t seed, std::uint64_t g, std::uint32_t cidx, float sigma, float& re, float& im)
+// Noise on cyclic-prefix sample cidx (0..cp-1): samples c and c + ceil(cp/2) share one Philox block.
+inline void cp_noise(std::uint64_t seed, std::uint64_t g, std::uint32_t cidx, std::uint32_t cp, float sigma, float& re, float& im)
 {
-    const std::uint32_t ctr[4] = { cidx, static_cast<std::uint32_t>(g), static_cast<std::uint32_t>(g >> 32), kStreamCp };
+    const std::uint32_t half = cp >= 2 ? (cp + 1) / 2 : 1;
+    const std::uint32_t ctr[4] = { cidx % half, static_cast<std::uint32_t>(g), static_cast<std::uint32_t>(g >> 32), kStreamCp };
     const std::uint32_t key[2] = { static_cast<std::uint32_t>(seed), static_cast<std::uint32_t>(seed >> 32) };
     std::uint32_t r[4];
     philox4x32_10(ctr, key, r);
-    gaussian_pair(r[0], r[1], sigma, re, im);
+    const std::uint32_t h = (cidx / half) & 1u;
+    gaussian_pair(r[2 * h], r[2 * h + 1], sigma, re, im);
 }
 
 // One transmitted+received OFDM symbol (model: app/QFDemoWindow.cpp:201-224 with a channel
@@ -466,7 +474,7 @@ void generate_symbol(const Constellation& c, std::uint32_t n_fft, std::uint32_t 
     ofdm_tx<float>(freq.data(), n_fft, cp, rx_out);
     for (std::uint32_t i = 0; i < cp; ++i) {
         float nr, ni;
-        cp_noise(seed, g, i, sigma, nr, ni);
+        cp_noise(seed, g, i, cp, sigma, nr, ni);
         rx_out[2 * i] += nr;
         rx_out[2 * i + 1] += ni;
     }
@@ -725,7 +733,14 @@ void orc_payload_noise(std::uint64_t seed, std::uint64_t g, std::uint32_t n, std
 {
     payload_noise(seed, g, n, n_fft, sigma, out2[0], out2[1]);
 }
-void orc_cp_noise(std::uint64_t seed, std::uint64_t g, std::uint32_t c, float sigma, float* out2) { cp_noise(seed, g, c, sigma, out2[0], out2[1]); }
+void orc_cp_noise(std::uint64_t seed, std::uint64_t g, std::uint32_t c, std::uint32_t cp, float sigma, float* out2) { cp_noise(seed, g, c, cp, sigma, out2[0], out2[1]); }
+void orc_gaussian_pair(std::uint32_t x1, std::uint32_t x2, float sigma, float* out2) { gaussian_pair(x1, x2, sigma, out2[0], out2[1]); }
+void orc_rng_tables(float* out /* 64 + 512: (r_i, L_i) pairs, then (sin, cos) pairs */)
+{
+    const RngTables& t = rng_tables();
+    for (int i = 0; i < 32; ++i) { out[2 * i] = t.ln_r[i]; out[2 * i + 1] = t.ln_l[i]; }
+    for (int j = 0; j < 256; ++j) { out[64 + 2 * j] = t.sn[j]; out[64 + 2 * j + 1] = t.cs[j]; }
+}
 float orc_ln_unit(float x) { return ln_unit(x); }
 void orc_sincos_turn(std::uint32_t k24, float* out2) { sincos_turn(k24, out2[0], out2[1]); }
 

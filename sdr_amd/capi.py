@@ -70,6 +70,7 @@ class LinkArgs(Structure):
 
 
 POINT_HARD_ONLY = 1     # sdr_sweep_point.flags: hard decisions only, counters 5 and 6 untouched
+SWEEP_ZERO_COUNTERS = 1     # sdr_sweep_args.flags: the call clears the counters ahead of the launch
 
 
 class SweepPoint(Structure):
@@ -92,6 +93,8 @@ class SweepArgs(Structure):
         ("seed", c_uint64),
         ("points", POINTER(SweepPoint)),
         ("d_counters", c_void_p),
+        ("flags", c_uint32),
+        ("reserved", c_uint32),
     ]
 
 
@@ -188,6 +191,7 @@ SIGNATURES = {
     "sdr_diag_copy_shape_c32": (c_int, [c_void_p, c_void_p, c_uint32, c_uint32, c_uint32, c_uint64, c_void_p]),
     "sdr_diag_set_tuning": (c_int, [c_char_p, ctypes.c_long]),
     "sdr_zf_taps_c32": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_float, c_void_p, c_void_p]),
+    "sdr_zf_taps_host_c32": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_float, c_void_p, c_void_p]),
     "sdr_soft_demap_c32": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p, c_float, c_void_p]),
     "sdr_soft_demap_host_c32": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p, c_float, c_void_p]),
     "sdr_link_generate_c32": (c_int, [c_void_p, POINTER(LinkArgs)]),
@@ -197,6 +201,7 @@ SIGNATURES = {
     "sdr_link_chain_workspace": (c_int, [POINTER(ChainArgs), POINTER(c_uint64)]),
     "sdr_link_chain_c32": (c_int, [c_void_p, POINTER(ChainArgs)]),
     "sdr_philox4x32_10": (c_int, [POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32)]),
+    "sdr_rng_tables_f32": (c_int, [c_void_p]),
     "sdr_pipe_create": (c_int, [c_int, POINTER(PipeConfig), POINTER(c_void_p)]),
     "sdr_pipe_acquire": (c_int, [c_void_p, POINTER(c_void_p)]),
     "sdr_pipe_submit": (c_int, [c_void_p, c_uint64]),

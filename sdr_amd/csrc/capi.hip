@@ -236,6 +236,25 @@ int sdr_zf_taps_c32(sdr_ctx* ctx, int mod, const void* d_chan, size_t n, float i
     return zf_taps_dev(ctx, mod, d_chan, n, inv_n0, d_taps, d_weight);
 }
 
+int sdr_zf_taps_host_c32(sdr_ctx* ctx, int mod, const void* h_chan, size_t n, float inv_n0, void* h_taps, float* h_weight)
+{
+    SDR_TRY(ensure_device(ctx));
+    if (!valid_mod(mod)) return fail(SDR_ERR_INVALID, "unknown modulation %d", mod);
+    if (n == 0) return SDR_OK;
+    if (!h_chan || !h_taps || !h_weight) return fail(SDR_ERR_INVALID, "null host pointer");
+    auto up = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
+    const size_t o_taps = up(n * 8), o_w = o_taps + up(n * 8);
+    void* arena_v = nullptr;
+    SDR_TRY(get_staging(ctx, 3, o_w + up(n * 4), &arena_v));
+    unsigned char* arena = static_cast<unsigned char*>(arena_v);
+    SDR_HIP(hipMemcpyAsync(arena, h_chan, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    SDR_TRY(zf_taps_dev(ctx, mod, arena, n, inv_n0, arena + o_taps, reinterpret_cast<float*>(arena + o_w)));
+    SDR_HIP(hipMemcpyAsync(h_taps, arena + o_taps, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    SDR_HIP(hipMemcpyAsync(h_weight, arena + o_w, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    SDR_HIP(hipStreamSynchronize(ctx->stream));
+    return SDR_OK;
+}
+
 int sdr_soft_demap_c32(sdr_ctx* ctx, int mod, const void* d_sym, size_t n_sym, const float* d_weight, float weight0, float* d_llr)
 {
     SDR_TRY(ensure_device(ctx));

@@ -66,6 +66,15 @@ struct sdr_ctx {
     // kCounterSlots x 8 partial counters; kernels add into slot (workgroup id mod kCounterSlots),
     // fold_counters() sums them into the caller's eight and leaves them zero again.
     unsigned long long* counter_slots = nullptr;
+    // host copy of the point table of the last sweep and where its device copy lies (link_sweep reuses it)
+    std::vector<unsigned char> sweep_table;
+    void* sweep_table_dev = nullptr;
+    // tables of the Gaussian generator (rng.hpp), built on first use
+    void* rng_tables = nullptr;
+    // sdr_ofdm_demod_noalloc_c32 (noalloc.hip): this device's static scratch array and the counter-slot
+    // set inside it that this context owns (-1: none free when the context was made)
+    unsigned char* noalloc_base = nullptr;
+    int noalloc_slot_set = -1;
 };
 
 namespace sdr {
@@ -87,5 +96,8 @@ int fold_counter_slots(sdr_ctx* ctx, unsigned long long* slots, unsigned long lo
 // Host-side generation of the reference's per-stage twiddle sequence (lib/inc/fft.hpp:113-150).
 void make_twiddles_f32(size_t n, bool inverse, float* out);
 void make_twiddles_f64(size_t n, bool inverse, double* out);
+// Tables of the Gaussian generator (rng.hpp): 2 * (32 + 256) floats on the host / cached on the device.
+void make_rng_tables_f32(float* out);
+int get_rng_tables(sdr_ctx* ctx, const float2** d_tables);
 
 } // namespace sdr

@@ -100,6 +100,38 @@ int get_twiddles(sdr_ctx* ctx, size_t n, bool inverse, bool is_double, const voi
     return SDR_OK;
 }
 
+// Tables of the Gaussian generator (rng.hpp): 32 pairs (r_i, L_i) and 256 pairs (sin, cos), every entry a double
+// result rounded to float (a CPU restatement of the generator builds the same with the same libm).
+void make_rng_tables_f32(float* out)
+{
+    for (int i = 0; i < 32; ++i) {
+        const double c = 1.0 + (static_cast<double>(i) + 0.5) / 32.0;
+        const float r = static_cast<float>(1.0 / c);
+        out[2 * i] = r;
+        out[2 * i + 1] = static_cast<float>(-std::log(static_cast<double>(r)));
+    }
+    for (int j = 0; j < 256; ++j) {
+        const double a = 2.0 * 3.14159265358979323846264338327950288 * static_cast<double>(j) / 256.0;
+        out[64 + 2 * j] = static_cast<float>(std::sin(a));
+        out[64 + 2 * j + 1] = static_cast<float>(std::cos(a));
+    }
+}
+
+int get_rng_tables(sdr_ctx* ctx, const float2** d_tables)
+{
+    if (!ctx->rng_tables) {
+        float host[2 * (32 + 256)];
+        make_rng_tables_f32(host);
+        void* d = nullptr;
+        SDR_HIP(hipMalloc(&d, sizeof(host)));
+        hipError_t e = hipMemcpy(d, host, sizeof(host), hipMemcpyHostToDevice);      // synchronous, one-off per context
+        if (e != hipSuccess) { (void)hipFree(d); return fail_hip(e, "hipMemcpy(rng tables)"); }
+        ctx->rng_tables = d;
+    }
+    *d_tables = static_cast<const float2*>(ctx->rng_tables);
+    return SDR_OK;
+}
+
 int get_staging(sdr_ctx* ctx, int slot, size_t bytes, void** ptr)
 {
     Staging& s = ctx->stage[slot];
@@ -239,7 +271,8 @@ static int create_common(int device, hipStream_t borrowed, bool borrow, sdr_ctx*
     ctx->lds_max = prop.sharedMemPerBlockOptin ? prop.sharedMemPerBlockOptin : prop.sharedMemPerBlock;
     if (ctx->lds_max < prop.sharedMemPerBlock) ctx->lds_max = prop.sharedMemPerBlock;
     // the allocation-free entry point's static array: address and tables resolved here, once per device
-    if (int rc = noalloc_setup_device(device); rc != SDR_OK) { sdr_destroy(ctx); return rc; }
+    // (a failure there is that entry point's to report, not this one's)
+    noalloc_attach(ctx);
     *out = ctx;
     return SDR_OK;
 }
@@ -258,6 +291,8 @@ void sdr_destroy(sdr_ctx* ctx)
     for (auto& kv : ctx->twiddles) (void)hipFree(kv.second);
     for (auto& s : ctx->stage) if (s.ptr) (void)hipFree(s.ptr);
     if (ctx->counter_slots) (void)hipFree(ctx->counter_slots);
+    if (ctx->rng_tables) (void)hipFree(ctx->rng_tables);
+    noalloc_detach(ctx);
     if (ctx->aux_stream) { (void)hipStreamSynchronize(ctx->aux_stream); (void)hipStreamDestroy(ctx->aux_stream); }
     for (int i = 0; i < 2; ++i) {
         if (ctx->chain_generated[i]) (void)hipEventDestroy(ctx->chain_generated[i]);
@@ -284,6 +319,13 @@ int sdr_twiddle_table_c32(size_t n, int inverse, float* h_out)
     if (n < 2) return SDR_OK;
     if (!is_pow2(n)) return fail(SDR_ERR_NOT_POW2, "%s", kPow2Message);
     make_twiddles_f32(n, inverse != 0, h_out);
+    return SDR_OK;
+}
+
+int sdr_rng_tables_f32(float* h_out)
+{
+    if (!h_out) return fail(SDR_ERR_INVALID, "null output");
+    make_rng_tables_f32(h_out);
     return SDR_OK;
 }
 

@@ -11,6 +11,17 @@ namespace sdr {
 
 namespace {
 
+// One wave exchanging data through LDS: the hardware serves a wave's LDS instructions in order, so no
+// s_barrier is needed -- but the compiler must not move the loads above the other lanes' stores.  The bare
+// wave barrier intrinsic carries no memory semantics; the wavefront-scope fences do.
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+
 constexpr unsigned kThreads = 256;
 #ifndef SDR_ELEM_XCD
 #define SDR_ELEM_XCD 1
@@ -177,7 +188,7 @@ __global__ void __launch_bounds__(256) from_constl_kernel(const T* __restrict__ 
             }
             mine[j * 64 + lane] = static_cast<uint16_t>(idx);
         }
-        __builtin_amdgcn_wave_barrier();     // one wave: its LDS operations complete in order
+        wave_lds_sync();     // one wave: its LDS operations complete in order
         if (words_ok && k0 + 512 <= n_sym) {
             // A whole tile = 64 * BPS bytes = 16 * BPS four-byte words of the MSB-first stream: lane j builds word j from
             // the (at most CNT) symbols that overlap it, so that a store instruction writes 256 contiguous bytes.  (A lane
@@ -198,7 +209,7 @@ __global__ void __launch_bounds__(256) from_constl_kernel(const T* __restrict__ 
                     out32[j] = __builtin_bswap32(static_cast<uint32_t>(acc >> (CNT * BPS - off - 32)));
                 }
             }
-            __builtin_amdgcn_wave_barrier();
+            wave_lds_sync();
             continue;
         }
         unsigned long long lo = 0;           // bit stream of the group, MSB first: 8 * BPS <= 80 bits
@@ -209,7 +220,7 @@ __global__ void __launch_bounds__(256) from_constl_kernel(const T* __restrict__ 
             if constexpr (8 * BPS > 64) hi = (hi << BPS) | static_cast<unsigned>(lo >> (64 - BPS));
             lo = (lo << BPS) | idx;
         }
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_sync();
         const size_t first = (k0 / 8 + lane) * BPS;
 #pragma unroll
         for (int b = 0; b < BPS; ++b) {
@@ -255,7 +266,7 @@ __global__ void __launch_bounds__(256) soft_demap_kernel(const float* __restrict
 #pragma unroll
                     for (int b = 0; b < BPS; ++b) mine[lane * BPS + b] = l[b];
                 }
-                __builtin_amdgcn_wave_barrier();     // one wave: its LDS operations complete in order
+                wave_lds_sync();     // one wave: its LDS operations complete in order
                 const size_t n_here = (range.last - k0 < 64 ? range.last - k0 : 64) * BPS;      // floats of this wave's span
                 float* dst = llr + k0 * BPS;
 #pragma unroll
@@ -270,7 +281,7 @@ __global__ void __launch_bounds__(256) soft_demap_kernel(const float* __restrict
                         for (size_t j = f; j < n_here && j < f + 4; ++j) dst[j] = mine[j];
                     }
                 }
-                __builtin_amdgcn_wave_barrier();
+                wave_lds_sync();
                 continue;
             }
         }

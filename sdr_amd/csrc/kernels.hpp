@@ -30,8 +30,10 @@ struct RxWorkspace {
     unsigned long long* counter_slots = nullptr;   // kCounterSlots x 8, all zero
 };
 int rx_fused_launch(sdr_ctx* ctx, const sdr_demod_args& a, const RxWorkspace* ws = nullptr);
-// noalloc.hip: resolves the static scratch array of `device` (once per device) -- called by sdr_create
-int noalloc_setup_device(int device);
+// noalloc.hip: resolves the static scratch array of the context's device (once per device; a failure is kept for
+// sdr_ofdm_demod_noalloc_c32 to report and does not fail sdr_create) and claims a counter-slot set for the context
+void noalloc_attach(sdr_ctx* ctx);
+void noalloc_detach(sdr_ctx* ctx);
 int rx_fft_only_launch(sdr_ctx* ctx, const void* d_in, uint32_t n_fft, uint32_t cp, uint64_t n_sym, void* d_out);
 // measurement aid (sdr_amd_diag.h): changes a run-time tuning knob of the receive kernels
 int rx_set_tuning(const char* name, long value);

@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 namespace sdr {
@@ -21,7 +22,7 @@ namespace sdr {
 #define SDR_DECL_LINK(L) \
     int tx_fused_dispatch_##L(sdr_ctx*, const TxParams&, int); \
     int mc_fused_dispatch_##L(sdr_ctx*, const McParams&, int); \
-    int sweep_fused_dispatch_##L(sdr_ctx*, const SweepPointDev*, uint32_t, unsigned long long, const float2*, unsigned long long, unsigned long long*); \
+    int sweep_fused_dispatch_##L(sdr_ctx*, const SweepPointDev*, uint32_t, unsigned long long, const float2*, const float2*, unsigned long long, unsigned long long*); \
     int sweep_symbols_per_group_##L();
 SDR_DECL_LINK(6) SDR_DECL_LINK(7) SDR_DECL_LINK(8) SDR_DECL_LINK(9) SDR_DECL_LINK(10) SDR_DECL_LINK(11) SDR_DECL_LINK(12) SDR_DECL_LINK(13)
 #undef SDR_DECL_LINK
@@ -56,18 +57,18 @@ int mc_dispatch(sdr_ctx* ctx, unsigned log2n, const McParams& p, int mod)
         default: return fail(SDR_ERR_UNSUPPORTED, "n_fft = 2^%u has no fused kernel", log2n);
     }
 }
-int sweep_dispatch(sdr_ctx* ctx, unsigned log2n, const SweepPointDev* d_pts, uint32_t n_points, unsigned long long blocks, const float2* tw, unsigned long long seed,
-                   unsigned long long* counters)
+int sweep_dispatch(sdr_ctx* ctx, unsigned log2n, const SweepPointDev* d_pts, uint32_t n_points, unsigned long long blocks, const float2* tw, const float2* rng,
+                   unsigned long long seed, unsigned long long* counters)
 {
     switch (log2n) {
-        case 6: return sweep_fused_dispatch_6(ctx, d_pts, n_points, blocks, tw, seed, counters);
-        case 7: return sweep_fused_dispatch_7(ctx, d_pts, n_points, blocks, tw, seed, counters);
-        case 8: return sweep_fused_dispatch_8(ctx, d_pts, n_points, blocks, tw, seed, counters);
-        case 9: return sweep_fused_dispatch_9(ctx, d_pts, n_points, blocks, tw, seed, counters);
-        case 10: return sweep_fused_dispatch_10(ctx, d_pts, n_points, blocks, tw, seed, counters);
-        case 11: return sweep_fused_dispatch_11(ctx, d_pts, n_points, blocks, tw, seed, counters);
-        case 12: return sweep_fused_dispatch_12(ctx, d_pts, n_points, blocks, tw, seed, counters);
-        case 13: return sweep_fused_dispatch_13(ctx, d_pts, n_points, blocks, tw, seed, counters);
+        case 6: return sweep_fused_dispatch_6(ctx, d_pts, n_points, blocks, tw, rng, seed, counters);
+        case 7: return sweep_fused_dispatch_7(ctx, d_pts, n_points, blocks, tw, rng, seed, counters);
+        case 8: return sweep_fused_dispatch_8(ctx, d_pts, n_points, blocks, tw, rng, seed, counters);
+        case 9: return sweep_fused_dispatch_9(ctx, d_pts, n_points, blocks, tw, rng, seed, counters);
+        case 10: return sweep_fused_dispatch_10(ctx, d_pts, n_points, blocks, tw, rng, seed, counters);
+        case 11: return sweep_fused_dispatch_11(ctx, d_pts, n_points, blocks, tw, rng, seed, counters);
+        case 12: return sweep_fused_dispatch_12(ctx, d_pts, n_points, blocks, tw, rng, seed, counters);
+        case 13: return sweep_fused_dispatch_13(ctx, d_pts, n_points, blocks, tw, rng, seed, counters);
         default: return fail(SDR_ERR_UNSUPPORTED, "n_fft = 2^%u has no fused kernel", log2n);
     }
 }
@@ -130,7 +131,7 @@ __global__ void gen_freq_kernel(uint32_t n_fft, uint64_t seed, uint64_t g0, uint
     }
 }
 
-__global__ void add_noise_kernel(uint32_t n_fft, uint32_t cp, uint64_t seed, uint64_t g0, uint64_t n_sym, float sigma, float2* __restrict__ rx)
+__global__ void add_noise_kernel(uint32_t n_fft, uint32_t cp, uint64_t seed, uint64_t g0, uint64_t n_sym, float sigma, const float2* __restrict__ rng, float2* __restrict__ rx)
 {
     const uint32_t len = n_fft + cp;
     const size_t total = size_t(n_sym) * len;
@@ -138,7 +139,7 @@ __global__ void add_noise_kernel(uint32_t n_fft, uint32_t cp, uint64_t seed, uin
         const size_t s = e / len;
         const uint32_t i = static_cast<uint32_t>(e - s * len);
         const uint64_t g = g0 + s;
-        const float2 nz = (i < cp) ? cp_noise(seed, g, i, sigma) : payload_noise(seed, g, i - cp, n_fft, sigma);
+        const float2 nz = (i < cp) ? cp_noise(seed, g, i, cp, sigma, rng) : payload_noise(seed, g, i - cp, n_fft, sigma, rng);
         float2 v = rx[e];
         v.x = v.x + nz.x;
         v.y = v.y + nz.y;
@@ -179,10 +180,13 @@ int link_generate(sdr_ctx* ctx, const sdr_link_args& a)
     SDR_TRY(check_link(a));
     if (a.n_sym == 0) return SDR_OK;
     if (!a.d_rx) return fail(SDR_ERR_INVALID, "null d_rx");
+    const float2* rng = nullptr;
+    SDR_TRY(get_rng_tables(ctx, &rng));
     if (!generic_only() && rx_fused_supported(a.n_fft, a.mod) && is_aligned(a.d_rx, 8) && is_aligned(a.d_tx_bits, 4) && is_aligned(a.d_chan, 8)) {
         const void* tw = nullptr;
         SDR_TRY(get_twiddles(ctx, a.n_fft, true, false, &tw));
         TxParams p = {};
+        p.rng = rng;
         p.tw_inv = static_cast<const float2*>(tw);
         p.chan = static_cast<const float2*>(a.d_chan);
         p.out = static_cast<float2*>(a.d_rx);
@@ -208,7 +212,7 @@ int link_generate(sdr_ctx* ctx, const sdr_link_args& a)
     SDR_TRY(fft_generic_f32(ctx, freq, a.d_rx, a.n_fft, true, a.n_fft, 0, size_t(a.n_fft) + a.cp, a.cp, a.cp, a.n_sym));
     const size_t samples = size_t(a.n_sym) * (size_t(a.n_fft) + a.cp);
     hipLaunchKernelGGL(add_noise_kernel, dim3(grid_for(ctx, samples)), dim3(kThreads), 0, ctx->stream, a.n_fft, a.cp, a.seed, a.first_symbol, a.n_sym, a.sigma,
-                       static_cast<float2*>(a.d_rx));
+                       rng, static_cast<float2*>(a.d_rx));
     SDR_HIP(hipGetLastError());
     if (a.d_tx_bits) {
         const size_t n_bytes = total * a.mod / 8;
@@ -249,6 +253,7 @@ int link_ber(sdr_ctx* ctx, const sdr_link_args& a)
         SDR_TRY(get_twiddles(ctx, a.n_fft, false, false, &twf));
         SDR_TRY(get_twiddles(ctx, a.n_fft, true, false, &twi));
         McParams p = {};
+        SDR_TRY(get_rng_tables(ctx, &p.rng));
         p.tw_fwd = static_cast<const float2*>(twf);
         p.tw_inv = static_cast<const float2*>(twi);
         p.counters = reinterpret_cast<unsigned long long*>(a.d_counters);
@@ -300,9 +305,11 @@ int link_sweep(sdr_ctx* ctx, const sdr_sweep_args& a)
     if (a.struct_size != sizeof(sdr_sweep_args)) return fail(SDR_ERR_INVALID, "sdr_sweep_args.struct_size %u != %zu", a.struct_size, sizeof(sdr_sweep_args));
     if (a.n_fft == 0 || !is_pow2(a.n_fft)) return fail(SDR_ERR_NOT_POW2, "%s", kPow2Message);
     if (a.cp > a.n_fft) return fail(SDR_ERR_INVALID, "cyclic prefix %u longer than the FFT %u", a.cp, a.n_fft);
+    if (a.flags & ~static_cast<uint32_t>(SDR_SWEEP_ZERO_COUNTERS)) return fail(SDR_ERR_INVALID, "sdr_sweep_args: unknown flags 0x%x", a.flags);
     if (a.n_points == 0) return SDR_OK;
     if (!a.points) return fail(SDR_ERR_INVALID, "null points");
     if (!a.d_counters) return fail(SDR_ERR_INVALID, "null d_counters");
+    if (a.flags & SDR_SWEEP_ZERO_COUNTERS) SDR_HIP(hipMemsetAsync(a.d_counters, 0, size_t(a.n_points) * 8 * sizeof(uint64_t), ctx->stream));
     bool fused = !generic_only();
     for (uint32_t i = 0; i < a.n_points; ++i) {
         const sdr_sweep_point& pt = a.points[i];
@@ -381,20 +388,32 @@ int link_sweep(sdr_ctx* ctx, const sdr_sweep_args& a)
     }
     const void* twf = nullptr;
     SDR_TRY(get_twiddles(ctx, a.n_fft, false, false, &twf));
+    // The device copy of the table is kept: a sweep that repeats the previous one (a timed repetition, the next
+    // noise seed of the same grid) skips the pinned-buffer hand-over and the host-to-device copy.
     void* d_table = nullptr;
-    SDR_TRY(upload_table(ctx, table.data(), table.size() * sizeof(SweepPointDev), 8, &d_table));
-    return sweep_dispatch(ctx, log2n, static_cast<const SweepPointDev*>(d_table), static_cast<uint32_t>(table.size()), blocks, static_cast<const float2*>(twf), a.seed,
+    const size_t table_bytes = table.size() * sizeof(SweepPointDev);
+    if (ctx->sweep_table.size() == table_bytes && ctx->sweep_table_dev && ctx->sweep_table_dev == ctx->stage[8].ptr &&
+        memcmp(ctx->sweep_table.data(), table.data(), table_bytes) == 0) {
+        d_table = ctx->sweep_table_dev;
+    } else {
+        SDR_TRY(upload_table(ctx, table.data(), table_bytes, 8, &d_table));
+        ctx->sweep_table.assign(reinterpret_cast<const unsigned char*>(table.data()), reinterpret_cast<const unsigned char*>(table.data()) + table_bytes);
+        ctx->sweep_table_dev = d_table;
+    }
+    const float2* rng = nullptr;
+    SDR_TRY(get_rng_tables(ctx, &rng));
+    return sweep_dispatch(ctx, log2n, static_cast<const SweepPointDev*>(d_table), static_cast<uint32_t>(table.size()), blocks, static_cast<const float2*>(twf), rng, a.seed,
                           reinterpret_cast<unsigned long long*>(a.d_counters));
 }
 
 namespace {
 
-__global__ void channel_kernel(uint32_t n_fft, uint64_t seed, uint64_t first_set, size_t n_sets, float2* __restrict__ chan)
+__global__ void channel_kernel(uint32_t n_fft, uint64_t seed, uint64_t first_set, size_t n_sets, const float2* __restrict__ rng, float2* __restrict__ chan)
 {
     const size_t total = n_sets * n_fft;
     for (size_t e = blockIdx.x * size_t(blockDim.x) + threadIdx.x; e < total; e += size_t(gridDim.x) * blockDim.x) {
         const size_t s = e / n_fft;
-        chan[e] = chan_sample(seed, first_set + s, static_cast<uint32_t>(e - s * n_fft));
+        chan[e] = chan_sample(seed, first_set + s, static_cast<uint32_t>(e - s * n_fft), rng);
     }
 }
 
@@ -444,7 +463,9 @@ int link_channel(sdr_ctx* ctx, uint32_t n_fft, uint64_t seed, uint64_t first_set
 {
     if (n_fft == 0 || n_sets == 0) return SDR_OK;
     if (!d_chan) return fail(SDR_ERR_INVALID, "null d_chan");
-    hipLaunchKernelGGL(channel_kernel, dim3(grid_for(ctx, n_sets * n_fft)), dim3(kThreads), 0, ctx->stream, n_fft, seed, first_set, n_sets, static_cast<float2*>(d_chan));
+    const float2* rng = nullptr;
+    SDR_TRY(get_rng_tables(ctx, &rng));
+    hipLaunchKernelGGL(channel_kernel, dim3(grid_for(ctx, n_sets * n_fft)), dim3(kThreads), 0, ctx->stream, n_fft, seed, first_set, n_sets, rng, static_cast<float2*>(d_chan));
     SDR_HIP(hipGetLastError());
     return SDR_OK;
 }
@@ -483,6 +504,7 @@ int link_chain(sdr_ctx* ctx, const sdr_chain_args& a)
     const void* tw = nullptr;
     SDR_TRY(get_twiddles(ctx, a.n_fft, false, false, &tw));
     SDR_TRY(get_twiddles(ctx, a.n_fft, true, false, &tw));
+    { const float2* rng = nullptr; SDR_TRY(get_rng_tables(ctx, &rng)); }
     if (a.d_counters) { unsigned long long* slots = nullptr; SDR_TRY(get_counter_slots(ctx, &slots)); }
     unsigned char* ws = static_cast<unsigned char*>(a.d_workspace);
     hipStream_t main_stream = ctx->stream;
@@ -510,24 +532,35 @@ int link_chain(sdr_ctx* ctx, const sdr_chain_args& a)
         SDR_HIP(hipEventRecord(ctx->chain_generated[b], gen_stream));
         return SDR_OK;
     };
-    SDR_TRY(generate(0));
-    for (uint64_t c = 0; c < n_chunks; ++c) {
-        const int b = static_cast<int>(c & 1);
-        if (c + 1 < n_chunks) SDR_TRY(generate(c + 1));          // queued before the demodulation of chunk c: runs beside it
-        const uint64_t done = c * l.chunk;
-        const uint64_t now = a.n_sym - done < l.chunk ? a.n_sym - done : l.chunk;
-        SDR_HIP(hipStreamWaitEvent(main_stream, ctx->chain_generated[b], 0));
-        sdr_demod_args d = {};
-        d.struct_size = sizeof(sdr_demod_args);
-        d.n_fft = a.n_fft; d.cp = a.cp; d.mod = a.mod; d.n_sym = now; d.sym_per_set = a.sym_per_set;
-        d.d_rx = ws + l.rx[b];
-        d.d_eq = ws + l.taps[b];
-        d.d_llr_weight = reinterpret_cast<const float*>(ws + l.wgt[b]);
-        d.d_llr = a.no_llr ? nullptr : reinterpret_cast<float*>(ws + l.llr);
-        d.d_ref_hard = ws + l.bits[b];
-        d.d_counters = a.d_counters;
-        SDR_TRY(rx_fused_launch(ctx, d));
-        SDR_HIP(hipEventRecord(ctx->chain_consumed[b], main_stream));
+    auto run = [&]() -> int {
+        SDR_TRY(generate(0));
+        for (uint64_t c = 0; c < n_chunks; ++c) {
+            const int b = static_cast<int>(c & 1);
+            if (c + 1 < n_chunks) SDR_TRY(generate(c + 1));          // queued before the demodulation of chunk c: runs beside it
+            const uint64_t done = c * l.chunk;
+            const uint64_t now = a.n_sym - done < l.chunk ? a.n_sym - done : l.chunk;
+            SDR_HIP(hipStreamWaitEvent(main_stream, ctx->chain_generated[b], 0));
+            sdr_demod_args d = {};
+            d.struct_size = sizeof(sdr_demod_args);
+            d.n_fft = a.n_fft; d.cp = a.cp; d.mod = a.mod; d.n_sym = now; d.sym_per_set = a.sym_per_set;
+            d.d_rx = ws + l.rx[b];
+            d.d_eq = ws + l.taps[b];
+            d.d_llr_weight = reinterpret_cast<const float*>(ws + l.wgt[b]);
+            d.d_llr = a.no_llr ? nullptr : reinterpret_cast<float*>(ws + l.llr);
+            d.d_ref_hard = ws + l.bits[b];
+            d.d_counters = a.d_counters;
+            SDR_TRY(rx_fused_launch(ctx, d));
+            SDR_HIP(hipEventRecord(ctx->chain_consumed[b], main_stream));
+        }
+        return SDR_OK;
+    };
+    const int rc = run();
+    if (rc != SDR_OK) {
+        // A failure part-way leaves generator work queued on the auxiliary stream, still writing into the caller's
+        // workspace, with nothing on the context's stream ordered behind it: drain it before the caller hears of the
+        // failure and frees or reuses the workspace.  (The error text of `rc` is already recorded; failures here are ignored.)
+        if (gen_stream != main_stream) (void)hipStreamSynchronize(gen_stream);
+        return rc;
     }
     if (a.d_llr_chunk) *a.d_llr_chunk = a.no_llr ? nullptr : reinterpret_cast<float*>(ws + l.llr);
     return SDR_OK;

@@ -24,6 +24,7 @@ struct TxParams {
     const float2* freq;          // n_sym x N bins (SRC_GLOBAL) or null
     const float2* tw_inv;        // N-1 inverse twiddles
     const float2* chan;          // n_sets x N or null (generator only)
+    const float2* rng;           // tables of the Gaussian generator (NOISE only)
     float2* out;                 // n_sym x (N + cp)
     uint8_t* tx_bits;            // packed transmitted bits or null (generator only)
     unsigned long long n_sym;
@@ -39,6 +40,7 @@ struct TxParams {
 struct McParams {
     const float2* tw_fwd;
     const float2* tw_inv;
+    const float2* rng;           // tables of the Gaussian generator
     unsigned long long* counters;
     unsigned long long n_sym;
     unsigned long long seed;
@@ -128,7 +130,9 @@ struct TxShape {
 #endif
     static constexpr bool TIME_ALIAS = SDR_TX_TIME_ALIAS && !DIRECT && N * 8 * SPW <= DATA_BYTES;
     static constexpr int TIME_OFF = TIME_ALIAS ? 0 : (DATA_BYTES + TW_BYTES + IDX_BYTES + 15) & ~15;
-    static constexpr int LDS_BYTES = (TIME_ALIAS ? DATA_BYTES + TW_BYTES + IDX_BYTES : TIME_OFF + (DIRECT ? 0 : N * 8 * SPW)) + 16;
+    static constexpr int LDS_CORE = ((TIME_ALIAS ? DATA_BYTES + TW_BYTES + IDX_BYTES : TIME_OFF + (DIRECT ? 0 : N * 8 * SPW)) + 15) & ~15;
+    static constexpr int RNG_OFF = LDS_CORE;                      // tables of the Gaussian generator (rng.hpp), NOISE only
+    static constexpr int LDS_BYTES = LDS_CORE + (NOISE ? kRngBytes : 0) + 16;
     // one symbol group per workgroup as straight-line code (batched ofdm::tx: +20 % at N = 4096; the
     // ALU-bound generator: +2 to +7 % over runs of two)
     static constexpr bool LOOP = !SDR_TX_STRAIGHT;
@@ -169,6 +173,9 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
     __shared__ __attribute__((aligned(16))) unsigned char lds[S::LDS_BYTES];
     idx_t* lds_idx = reinterpret_cast<idx_t*>(lds + DATA_BYTES + TW_BYTES);
     float2* lds_time = reinterpret_cast<float2*>(lds + TIME_OFF) + slot_of(threadIdx.x, TPS) * N;   // this symbol's time-domain samples
+    [[maybe_unused]] const float2* lds_rng = reinterpret_cast<const float2*>(lds + S::RNG_OFF);
+    // (several barriers lie between this copy and the first Gaussian sample)
+    if constexpr (NOISE) rng_tables_to_lds(p.rng, reinterpret_cast<float2*>(lds + S::RNG_OFF), threadIdx.x, O::kWG);
 
     const int tid = threadIdx.x;
     const int slot = tid / TPS;
@@ -276,17 +283,26 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
             lds_time[A::out_reg(m) | addr.pos_last] = make_float2(x[m].x * INV_LEN, x[m].y * INV_LEN);
         });
         __syncthreads();
-        // cyclic prefix first (ofdm.hpp:21 copies the clean tail; its noise is a stream of its own)
+        // cyclic prefix first (ofdm.hpp:21 copies the clean tail; its noise is a stream of its own,
+        // samples c and c + ceil(cp/2) sharing one Philox block)
         if (active) {
+            if constexpr (NOISE) {
+                const int half = static_cast<int>(cp_half(p.cp));
 #pragma unroll 1
-            for (int c = t; c < cp; c += TPS) {
-                float2 v = lds_time[N - cp + c];
-                if constexpr (NOISE) {
-                    const float2 nz = cp_noise(p.seed, g, static_cast<uint32_t>(c), p.sigma);
-                    v.x = v.x + nz.x;
-                    v.y = v.y + nz.y;
+                for (int c = t; c < half && c < cp; c += TPS) {
+                    const Philox4 b = cp_block(p.seed, g, static_cast<uint32_t>(c));
+                    const float2 z0 = gaussian_pair(b.v[0], b.v[1], p.sigma, lds_rng);
+                    const float2 v0 = lds_time[N - cp + c];
+                    dst[c] = make_float2(v0.x + z0.x, v0.y + z0.y);
+                    if (c + half < cp) {
+                        const float2 z1 = gaussian_pair(b.v[2], b.v[3], p.sigma, lds_rng);
+                        const float2 v1 = lds_time[N - cp + c + half];
+                        dst[c + half] = make_float2(v1.x + z1.x, v1.y + z1.y);
+                    }
                 }
-                dst[c] = v;
+            } else {
+#pragma unroll 1
+                for (int c = t; c < cp; c += TPS) dst[c] = lds_time[N - cp + c];
             }
         }
         if constexpr (NOISE) {
@@ -295,8 +311,8 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
             for (int i = 0; i < E / 2; ++i) {                       // samples n and n + N/2 share one Philox block
                 const int n = i * TPS + t;
                 const Philox4 b = noise_block(p.seed, g, static_cast<uint32_t>(n));
-                const float2 z0 = gaussian_pair(b.v[0], b.v[1], p.sigma);
-                const float2 z1 = gaussian_pair(b.v[2], b.v[3], p.sigma);
+                const float2 z0 = gaussian_pair(b.v[0], b.v[1], p.sigma, lds_rng);
+                const float2 z1 = gaussian_pair(b.v[2], b.v[3], p.sigma, lds_rng);
                 const float2 a0 = lds_time[n], a1 = lds_time[n + N / 2];
                 lds_time[n] = make_float2(a0.x + z0.x, a0.y + z0.y);
                 lds_time[n + N / 2] = make_float2(a1.x + z1.x, a1.y + z1.y);
@@ -371,7 +387,8 @@ struct McLds {
     static constexpr bool TIME_ALIAS = SDR_MC_TIME_ALIAS && O::kN * 8 * O::kSPW <= DATA_BYTES;
     static constexpr int TIME_BYTES = TIME_ALIAS ? 0 : O::kN * 8 * O::kSPW;
     static constexpr int TIME_OFF = TIME_ALIAS ? 0 : DATA_BYTES + TW_BYTES;
-    static constexpr int BYTES = DATA_BYTES + TW_BYTES + TIME_BYTES + 16;
+    static constexpr int RNG_OFF = (DATA_BYTES + TW_BYTES + TIME_BYTES + 15) & ~15;      // tables of the Gaussian generator (rng.hpp)
+    static constexpr int BYTES = RNG_OFF + kRngBytes + 16;
 };
 
 // generate -> IFFT -> + noise -> FFT -> demap -> count for the symbol groups [grp_begin, grp_end) of
@@ -387,6 +404,7 @@ __device__ __forceinline__ void mc_body(const McWork& p, unsigned char* lds, con
     constexpr int N = O::kN, E = O::kE, TPS = O::kTPS, SPW = O::kSPW;
     constexpr int BPS = MI + MQ;
     float2* lds_time = reinterpret_cast<float2*>(lds + McLds<LOG2N>::TIME_OFF);
+    const float2* lds_rng = reinterpret_cast<const float2*>(lds + McLds<LOG2N>::RNG_OFF);      // filled by the kernel's set-up
     // aliased time buffer: other waves of the workgroup may still be inside the transform's last exchange
     constexpr bool ALIAS_SYNC = McLds<LOG2N>::TIME_ALIAS && O::kWG > 64;
     const int tid = threadIdx.x;
@@ -425,8 +443,8 @@ __device__ __forceinline__ void mc_body(const McWork& p, unsigned char* lds, con
         for (int i = 0; i < E / 2; ++i) {
             const int n = i * TPS + t;
             const Philox4 b = noise_block(p.seed, g, static_cast<uint32_t>(n));
-            const float2 z0 = gaussian_pair(b.v[0], b.v[1], p.sigma);
-            const float2 z1 = gaussian_pair(b.v[2], b.v[3], p.sigma);
+            const float2 z0 = gaussian_pair(b.v[0], b.v[1], p.sigma, lds_rng);
+            const float2 z1 = gaussian_pair(b.v[2], b.v[3], p.sigma, lds_rng);
             float2* lo = lds_time + slot * N + n;
             float2* hi = lo + N / 2;
             const float2 a0 = *lo, a1 = *hi;
@@ -510,6 +528,7 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) SDR_MC_ATTR mc_fused_kern
     // twiddle registers of this register-bound kernel.
     FftTwiddles<LOG2N> tw_fwd;
     tw_fwd.init(p.tw_fwd, reinterpret_cast<float2*>(lds + McLds<LOG2N>::DATA_BYTES), tid, addr);
+    rng_tables_to_lds(p.rng, reinterpret_cast<float2*>(lds + McLds<LOG2N>::RNG_OFF), tid, O::kWG);      // barriers follow before the first use
     if constexpr (O::kMidCount > 0) __syncthreads();
 
     const unsigned long long n_groups = (p.n_sym + SPW - 1) / SPW;
@@ -542,7 +561,7 @@ static_assert(sizeof(SweepPointDev) == 64, "one point per 64 bytes");
 
 template <int LOG2N>
 __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) SDR_MC_ATTR sweep_fused_kernel(const SweepPointDev* __restrict__ pts, uint32_t n_points, const float2* __restrict__ tw,
-                                                                                      unsigned long long seed, unsigned long long* __restrict__ counters)
+                                                                                      const float2* __restrict__ rng, unsigned long long seed, unsigned long long* __restrict__ counters)
 {
     using O = PlanOps<LOG2N>;
     __shared__ __attribute__((aligned(16))) unsigned char lds[McLds<LOG2N>::BYTES];
@@ -551,6 +570,7 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) SDR_MC_ATTR sweep_fused_k
     addr.init(tid % O::kTPS, tid / O::kTPS, O::max_sym_bytes());
     FftTwiddles<LOG2N> tw_fwd;
     tw_fwd.init(tw, reinterpret_cast<float2*>(lds + McLds<LOG2N>::DATA_BYTES), tid, addr);
+    rng_tables_to_lds(rng, reinterpret_cast<float2*>(lds + McLds<LOG2N>::RNG_OFF), tid, O::kWG);      // barriers follow before the first use
     if constexpr (O::kMidCount > 0) __syncthreads();
 
     // uniform over the workgroup: the table is read through scalar loads
@@ -621,12 +641,12 @@ int launch_tx_fused(sdr_ctx* ctx, const TxParams& p)
 }
 
 template <int LOG2N>
-int launch_sweep_fused(sdr_ctx* ctx, const SweepPointDev* d_pts, uint32_t n_points, unsigned long long blocks, const float2* tw, unsigned long long seed, unsigned long long* counters)
+int launch_sweep_fused(sdr_ctx* ctx, const SweepPointDev* d_pts, uint32_t n_points, unsigned long long blocks, const float2* tw, const float2* rng, unsigned long long seed, unsigned long long* counters)
 {
     using O = PlanOps<LOG2N>;
     if (blocks == 0) return SDR_OK;
     if (blocks > 0x7FFFFFFFull) return fail(SDR_ERR_UNSUPPORTED, "sweep too large for one launch");
-    hipLaunchKernelGGL((sweep_fused_kernel<LOG2N>), dim3(static_cast<unsigned>(blocks)), dim3(O::kWG), 0, ctx->stream, d_pts, n_points, tw, seed, counters);
+    hipLaunchKernelGGL((sweep_fused_kernel<LOG2N>), dim3(static_cast<unsigned>(blocks)), dim3(O::kWG), 0, ctx->stream, d_pts, n_points, tw, rng, seed, counters);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(e, "sweep_fused_kernel launch");
     return SDR_OK;

@@ -43,10 +43,10 @@ int SDR_CAT(mc_fused_dispatch_, SDR_LOG2N)(sdr_ctx* ctx, const McParams& p, int 
     }
 }
 
-int SDR_CAT(sweep_fused_dispatch_, SDR_LOG2N)(sdr_ctx* ctx, const SweepPointDev* d_pts, uint32_t n_points, unsigned long long blocks, const float2* tw, unsigned long long seed,
-                                               unsigned long long* counters)
+int SDR_CAT(sweep_fused_dispatch_, SDR_LOG2N)(sdr_ctx* ctx, const SweepPointDev* d_pts, uint32_t n_points, unsigned long long blocks, const float2* tw, const float2* rng,
+                                               unsigned long long seed, unsigned long long* counters)
 {
-    return launch_sweep_fused<SDR_LOG2N>(ctx, d_pts, n_points, blocks, tw, seed, counters);
+    return launch_sweep_fused<SDR_LOG2N>(ctx, d_pts, n_points, blocks, tw, rng, seed, counters);
 }
 
 int SDR_CAT(sweep_symbols_per_group_, SDR_LOG2N)() { return PlanOps<SDR_LOG2N>::kSPW; }

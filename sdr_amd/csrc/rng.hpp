@@ -1,7 +1,10 @@
 // rng.hpp -- counter-based randomness of the device frame generator / AWGN channel.
 // No reference counterpart.  Philox4x32-10 (Salmon et al., SC'11) plus
-// elementary functions written with +,-,* only (and one correctly rounded sqrt), so that a CPU
-// implementation of the same formulas yields identical bits (the build uses -ffp-contract=off).
+// elementary functions written with +,-,* only, one correctly rounded sqrt and two small tables of
+// correctly rounded doubles, so that a CPU implementation of the same formulas yields identical bits
+// (the build uses -ffp-contract=off).  Round 3: 32-bit uniform for the radius (tail to 6.66 sigma instead
+// of 5.77), table-based range reduction in ln and sincos (a third of the operations), two prefix samples
+// per Philox block.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -52,61 +55,55 @@ __device__ inline uint32_t tx_index(uint64_t seed, uint64_t g, uint32_t k, uint3
     return tx_lane(tx_block(seed, g, k % stride), (k / stride) & 7u, bps);
 }
 
-// ln(x) for x in [2^-24, 1]
-__device__ inline float ln_unit(float x)
+// Tables of the Gaussian generator (round 3), built on the host by make_rng_tables (context.hip) with the same
+// double-precision formulas a CPU restatement uses: kRngLn pairs (r_i, L_i) -- r_i = fl(1/c_i), L_i = fl(-ln r_i) for the centre
+// c_i = 1 + (i + 1/2)/32 of mantissa interval i -- followed by kRngSc pairs (sin, cos)(2 pi j / 256).  Kernels keep them
+// in LDS (fused kernels) or read them from device memory (generic kernels): `Tab` is any pointer to the float2 array.
+constexpr int kRngLn = 32, kRngSc = 256, kRngPairs = kRngLn + kRngSc;
+constexpr int kRngBytes = kRngPairs * 8;      // 2304
+
+// ln(x) for x in [2^-32, 1]: ln m = L_i + log1p(m r_i - 1), |m r_i - 1| < 1/63, log1p cut after the cubic term (< 2e-8)
+template <typename Tab>
+__device__ inline float ln_unit(float x, Tab tab)
 {
     const uint32_t bits = __float_as_uint(x);
-    int e = static_cast<int>(bits >> 23) - 127;
-    float m = __uint_as_float((bits & 0x007FFFFFu) | 0x3F800000u);
-    if (m > 1.41421356f) { m = m * 0.5f; e += 1; }
-    const float f = m - 1.0f;
+    const int e = static_cast<int>(bits >> 23) - 127;
+    const float m = __uint_as_float((bits & 0x007FFFFFu) | 0x3F800000u);
+    const float2 rl = tab[(bits >> 18) & 31u];
+    const float f = m * rl.x - 1.0f;
+    const float q = f * 0.333333343f + -0.5f;
     const float z = f * f;
-    float p = 7.0376836292e-2f;
-    p = p * f + -1.1514610310e-1f;
-    p = p * f + 1.1676998740e-1f;
-    p = p * f + -1.2420140846e-1f;
-    p = p * f + 1.4249322787e-1f;
-    p = p * f + -1.6668057665e-1f;
-    p = p * f + 2.0000714765e-1f;
-    p = p * f + -2.4999993993e-1f;
-    p = p * f + 3.3333331174e-1f;
-    float y = (p * f) * z;
+    const float p = z * q + f;
     const float fe = static_cast<float>(e);
-    y = y + fe * -2.12194440e-4f;
-    y = y + z * -0.5f;
-    float r = f + y;
-    r = r + fe * 0.693359375f;
-    return r;
+    return (fe * 0.693147182f + rl.y) + p;
 }
 
-// sin and cos of 2*pi*k24/2^24
-__device__ inline void sincos_turn(uint32_t k24, float& s, float& c)
+// sin and cos of 2*pi*k24/2^24: the nearest 256th of a turn from the table, the rest (|b| <= pi/256) by
+// sin b = b - b^3/6, cos b = 1 - b^2/2 and the addition theorems
+template <typename Tab>
+__device__ inline void sincos_turn(uint32_t k24, float& s, float& c, Tab tab)
 {
-    const uint32_t shifted = (k24 + 0x200000u) & 0xFFFFFFu;
-    const uint32_t quad = shifted >> 22;
-    const int32_t rem = static_cast<int32_t>(shifted & 0x3FFFFFu) - 0x200000;
-    const float th = (static_cast<float>(rem) * 2.384185791015625e-07f) * 1.57079637f;
-    const float z = th * th;
-    float ps = 2.75573192e-6f;
-    ps = ps * z + -1.98412698e-4f;
-    ps = ps * z + 8.33333333e-3f;
-    ps = ps * z + -1.66666667e-1f;
-    const float sn = th + (th * z) * ps;
-    float pc = 2.48015873e-5f;
-    pc = pc * z + -1.38888889e-3f;
-    pc = pc * z + 4.16666667e-2f;
-    pc = pc * z + -0.5f;
-    const float cs = 1.0f + z * pc;
-    s = (quad == 0) ? sn : (quad == 1) ? cs : (quad == 2) ? -sn : -cs;
-    c = (quad == 0) ? cs : (quad == 1) ? -sn : (quad == 2) ? -cs : sn;
+    const uint32_t hi = (k24 + 0x8000u) >> 16;
+    const int32_t lo = static_cast<int32_t>(k24) - static_cast<int32_t>(hi << 16);
+    const float b = static_cast<float>(lo) * 3.74507039e-7f;
+    const float z = b * b;
+    const float sb = b + (b * z) * -0.166666672f;
+    const float cb = 1.0f + z * -0.5f;
+    const float2 a = tab[kRngLn + (hi & 255u)];
+    s = a.x * cb + a.y * sb;
+    c = a.y * cb - a.x * sb;
 }
 
-__device__ inline float2 gaussian_pair(uint32_t x1, uint32_t x2, float sigma)
+// Box-Muller on a 32-bit uniform u1 in [2^-32, 1] and a 24-bit angle: |z| <= sqrt(64 ln 2) sigma = 6.66 sigma
+template <typename Tab>
+__device__ inline float2 gaussian_pair(uint32_t x1, uint32_t x2, float sigma, Tab tab)
 {
-    const float u1 = static_cast<float>((x1 >> 8) + 1u) * 5.9604644775390625e-08f;
-    const float rad = sqrtf(-2.0f * ln_unit(u1));   // correctly rounded (hipcc default); __fsqrt_rn is the native 1-ulp form
+    const float u1 = (static_cast<float>(x1) + 1.0f) * 2.3283064365386963e-10f;
+    float t = -2.0f * ln_unit(u1, tab);
+    t = (t > 0.0f) ? t : 0.0f;                      // u1 = 1: the table form of ln may come out a few 1e-9 above 0
+    const float rad = sqrtf(t);                     // correctly rounded (hipcc default); __fsqrt_rn is the native 1-ulp form
     float s, c;
-    sincos_turn(x2 >> 8, s, c);
+    sincos_turn(x2 >> 8, s, c, tab);
     const float a = sigma * rad;
     return make_float2(a * c, a * s);
 }
@@ -117,26 +114,43 @@ __device__ inline Philox4 noise_block(uint64_t seed, uint64_t g, uint32_t r)
     return philox4x32_10(r, static_cast<uint32_t>(g), static_cast<uint32_t>(g >> 32), kStreamNoise,
                          static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32));
 }
-__device__ inline float2 payload_noise(uint64_t seed, uint64_t g, uint32_t n, uint32_t n_fft, float sigma)
+template <typename Tab>
+__device__ inline float2 payload_noise(uint64_t seed, uint64_t g, uint32_t n, uint32_t n_fft, float sigma, Tab tab)
 {
     const uint32_t half = n_fft >= 2 ? n_fft / 2 : 1;
     const Philox4 b = noise_block(seed, g, n % half);
     const bool hi = ((n / half) & 1u) != 0;
-    return gaussian_pair(hi ? b.v[2] : b.v[0], hi ? b.v[3] : b.v[1], sigma);
+    return gaussian_pair(hi ? b.v[2] : b.v[0], hi ? b.v[3] : b.v[1], sigma, tab);
 }
-__device__ inline float2 cp_noise(uint64_t seed, uint64_t g, uint32_t cidx, float sigma)
+// Block shared by cyclic-prefix samples r and r + ceil(cp/2).
+__device__ inline uint32_t cp_half(uint32_t cp) { return cp >= 2 ? (cp + 1) / 2 : 1; }
+__device__ inline Philox4 cp_block(uint64_t seed, uint64_t g, uint32_t r)
 {
-    const Philox4 b = philox4x32_10(cidx, static_cast<uint32_t>(g), static_cast<uint32_t>(g >> 32), kStreamCp,
-                                    static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32));
-    return gaussian_pair(b.v[0], b.v[1], sigma);
+    return philox4x32_10(r, static_cast<uint32_t>(g), static_cast<uint32_t>(g >> 32), kStreamCp,
+                         static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32));
+}
+template <typename Tab>
+__device__ inline float2 cp_noise(uint64_t seed, uint64_t g, uint32_t cidx, uint32_t cp, float sigma, Tab tab)
+{
+    const uint32_t half = cp_half(cp);
+    const Philox4 b = cp_block(seed, g, cidx % half);
+    const bool hi = ((cidx / half) & 1u) != 0;
+    return gaussian_pair(hi ? b.v[2] : b.v[0], hi ? b.v[3] : b.v[1], sigma, tab);
 }
 
 // Channel coefficient of subcarrier k in set `set`: unit-variance complex Gaussian.
-__device__ inline float2 chan_sample(uint64_t seed, uint64_t set, uint32_t k)
+template <typename Tab>
+__device__ inline float2 chan_sample(uint64_t seed, uint64_t set, uint32_t k, Tab tab)
 {
     const Philox4 b = philox4x32_10(k, static_cast<uint32_t>(set), static_cast<uint32_t>(set >> 32), kStreamChan,
                                     static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32));
-    return gaussian_pair(b.v[0], b.v[1], 0.70710678f);
+    return gaussian_pair(b.v[0], b.v[1], 0.70710678f, tab);
+}
+
+// Copies the tables into a workgroup's LDS (the caller barriers before the first use).
+__device__ inline void rng_tables_to_lds(const float2* __restrict__ src, float2* lds_tab, int tid, int wg_threads)
+{
+    for (int i = tid; i < kRngPairs; i += wg_threads) lds_tab[i] = src[i];
 }
 
 } // namespace sdr

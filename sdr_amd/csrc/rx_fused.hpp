@@ -988,7 +988,7 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG * GROUP)
                     float* mine = stg + (((lane / TPS) * NBB + hb) * TPS + (lane % TPS)) * CB;
                     static_for<GO>([&](auto G) { constexpr int g = G; *reinterpret_cast<float2*>(mine + 2 * g) = x[h * GO + g]; });
                     if constexpr (hb == NBB - 1) {
-                        __builtin_amdgcn_wave_barrier();
+                        symbol_sync<true>();      // one wave: LDS serves its instructions in order, the fences keep the compiler from reordering them
                         constexpr int RUN = TPS * CB * NBB;                  // floats per symbol in the group
                         constexpr int NV = 64 * CB * NBB / 4;
                         static_assert(RUN % 4 == 0 && NV % 64 == 0, "whole vectors, whole wave");
@@ -1002,7 +1002,7 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG * GROUP)
                                 *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.fft + static_cast<size_t>(dsym) * N + O::reg_pos(LAST, h0 * GO)) + off) = q4;
                             }
                         });
-                        __builtin_amdgcn_wave_barrier();
+                        symbol_sync<true>();      // one wave: LDS serves its instructions in order, the fences keep the compiler from reordering them
                     }
                 });
             }
@@ -1114,7 +1114,7 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG * GROUP)
                             store_floats<CHUNK>(stg + (((lane / TPS) * NB + hb) * TPS + (lane % TPS)) * CHUNK, l);
                         }
                         if constexpr (hb == NB - 1) {
-                        __builtin_amdgcn_wave_barrier();
+                        symbol_sync<true>();      // one wave: LDS serves its instructions in order, the fences keep the compiler from reordering them
                         constexpr int gbits = O::kLogE - P::kR[LAST];
                         float* gbase = p.llr + (bin0 + O::reg_pos(LAST, h0 * GO) + ((tid & ~63) << gbits)) * BPS;
                         static_for<(NV + 63) / 64>([&](auto I) {
@@ -1145,7 +1145,7 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG * GROUP)
                                 }
                             }
                         });
-                        __builtin_amdgcn_wave_barrier();
+                        symbol_sync<true>();      // one wave: LDS serves its instructions in order, the fences keep the compiler from reordering them
                         }      // last block of the staged group
                     }
                 } else if constexpr (!HARDONLY) {

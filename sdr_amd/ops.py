@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 from . import capi
-from .capi import POINT_HARD_ONLY, ChainArgs, DemodArgs, LinkArgs, SweepArgs, SweepPoint, check
+from .capi import POINT_HARD_ONLY, SWEEP_ZERO_COUNTERS, ChainArgs, DemodArgs, LinkArgs, SweepArgs, SweepPoint, check
 
 MODS = {"bpsk": 1, "qpsk": 2, "16qam": 4, "64qam": 6, "256qam": 8, "1024qam": 10}
 
@@ -268,12 +268,14 @@ class Context:
         check(self.lib.sdr_link_ber_c32(self._h, ctypes.byref(a)))
         return counters
 
-    def link_sweep(self, n_fft: int, cp: int, seed: int, points, counters: Optional[torch.Tensor] = None, hard_only: bool = False) -> torch.Tensor:
+    def link_sweep(self, n_fft: int, cp: int, seed: int, points, counters: Optional[torch.Tensor] = None, hard_only: bool = False,
+                   zero_counters: bool = False) -> torch.Tensor:
         """sdr_link_sweep_c32: every (modulation, noise level) point of a sweep in ONE launch.
         points = sequence of (mod, sigma, llr_weight0, first_symbol, n_sym[, flags]); counters = int64
         tensor (n_points, 8) on the device, accumulated into (created zeroed when None).
         hard_only: SDR_POINT_HARD_ONLY on every point (bit / symbol errors from hard decisions, no LLRs:
-        counters 5 and 6 are left alone)."""
+        counters 5 and 6 are left alone).  zero_counters: SDR_SWEEP_ZERO_COUNTERS, the library clears `counters` on its
+        stream ahead of the launch instead of accumulating into them."""
         n = len(points)
         if counters is None:
             counters = torch.zeros((n, 8), dtype=torch.int64, device=self.torch_device)
@@ -289,6 +291,7 @@ class Context:
         a.n_fft, a.cp, a.n_points, a.seed = n_fft, cp, n, seed
         a.points = ctypes.cast(table, ctypes.POINTER(SweepPoint))
         a.d_counters = counters.data_ptr()
+        a.flags = SWEEP_ZERO_COUNTERS if zero_counters else 0
         check(self.lib.sdr_link_sweep_c32(self._h, ctypes.byref(a)))
         return counters
 

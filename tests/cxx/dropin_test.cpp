@@ -8,12 +8,24 @@
 #include <cstring>
 #include <deque>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "sdrlib/fft.hpp"
 #include "sdrlib/modulation.hpp"
 #include "sdrlib/ofdm.hpp"
 #include "sdrlib/pipe.hpp"
+
+// The CPU oracle (oracle/sdr_oracle.cpp, test infrastructure) as the arbiter of the equalised path: the same C entry
+// points tests/ reach through ctypes.
+extern "C" {
+int orc_link_channel_c32(std::uint32_t n_fft, std::uint64_t seed, std::uint64_t first_set, std::size_t n_sets, float* chan_out);
+int orc_zf_taps_f32(int bps, const float* chan, std::size_t n, float inv_n0, float* taps, float* wgt);
+int orc_link_generate_c32(std::uint32_t n_fft, std::uint32_t cp, int bps, std::uint64_t seed, std::uint64_t g0, std::size_t n_sym, std::uint32_t sym_per_set,
+                          float sigma, const float* chan, float* rx_out, std::uint8_t* tx_bits);
+int orc_demod_c32(std::uint32_t n_fft, std::uint32_t cp, int bps, std::size_t n_sym, std::uint32_t sym_per_set, const float* rx, const float* eq, const float* wgt,
+                  float w0, float* fft_out, float* llr_out, std::uint8_t* hard_out);
+}
 
 static int g_failed = 0;
 #define CHECK(cond) do { if (!(cond)) { std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond); ++g_failed; } } while (0)
@@ -106,6 +118,8 @@ static void extras()
     CHECK(modulation::e16QAM::table<double>[0] == std::complex<double>(-3, -3));
     CHECK(modulation::e16QAM::table<double>[6] == std::complex<double>(-1, 3));
     CHECK(modulation::e16QAM::table<float>[15] == std::complex<float>(1, 1));
+    static_assert(noexcept(modulation::e16QAM::nearest(std::declval<const std::complex<double>&>())) && noexcept(modulation::e16QAM::nearest(std::declval<const std::complex<float>&>())),
+                  "nearest is noexcept like the reference's (modulation.hpp:50)");
     CHECK(modulation::e16QAM::nearest(std::complex<double>(0.9, -0.2)) == 9);   // +3, -1
     CHECK(modulation::e16QAM::nearest(std::complex<float>(0.f, 0.f)) == 5);     // four-way tie: lowest index
     // odd symbol count: trailing symbol dropped (modulation.hpp:103)
@@ -134,6 +148,59 @@ static void extras()
             const int bit = (payload[k / 2] >> ((k % 2 ? 0 : 4) + 3 - b)) & 1;
             CHECK((l[k * 4 + b] < 0) == (bit == 1));
         }
+}
+
+// FFT -> equalise -> LLR behind the drop-in headers (the step north_star inserts between ofdm::rx, lib/inc/ofdm.hpp:45-54, and
+// modulation::from_constl, lib/inc/modulation.hpp:96-112): ofdm::zf_equaliser + ofdm::demod_batch(in, n, cp, equaliser)
+// against the oracle on the same samples, bit for bit; the same cases tests/test_gpu_parity.py pins through Python.
+template <typename Mod>
+static void equalised_demod(std::uint32_t n, std::uint32_t cp, std::size_t n_sym, std::uint32_t per, float sigma)
+{
+    constexpr int bps = int(Mod::bits_per_symbol);
+    const std::size_t n_sets = (n_sym + per - 1) / per;
+    std::vector<std::complex<float>> chan(n_sets * n);
+    CHECK(orc_link_channel_c32(n, 41, 0, n_sets, reinterpret_cast<float*>(chan.data())) == 0);
+    for (auto& h : chan) if (std::abs(h) < 0.1f) h += 0.3f;                    // keep |H| away from zero
+    std::vector<std::complex<float>> air(n_sym * (n + cp));
+    std::vector<std::uint8_t> bits(n_sym * n * bps / 8);
+    CHECK(orc_link_generate_c32(n, cp, bps, 9, 0, n_sym, per, sigma, reinterpret_cast<const float*>(chan.data()), reinterpret_cast<float*>(air.data()), bits.data()) == 0);
+    std::vector<std::complex<float>> taps(chan.size());
+    std::vector<float> wgt(chan.size()), llr(n_sym * n * bps);
+    std::vector<std::uint8_t> hard(bits.size());
+    CHECK(orc_zf_taps_f32(bps, reinterpret_cast<const float*>(chan.data()), chan.size(), 40.0f, reinterpret_cast<float*>(taps.data()), wgt.data()) == 0);
+    CHECK(orc_demod_c32(n, cp, bps, n_sym, per, reinterpret_cast<const float*>(air.data()), reinterpret_cast<const float*>(taps.data()), wgt.data(), 0.0f, nullptr,
+                        llr.data(), hard.data()) == 0);
+
+    auto eq = ofdm::zf_equaliser<Mod>(chan, 40.0f, per);
+    CHECK(eq.has_value());
+    if (!eq) return;
+    CHECK(eq->taps == taps && eq->weights == wgt && eq->sym_per_set == per);
+    auto d = ofdm::demod_batch<Mod>(air, n, cp, *eq);
+    CHECK(d.has_value());
+    if (!d) { std::printf("demod_batch: %s\n", d.error().c_str()); return; }
+    CHECK(d->hard == hard);
+    CHECK(d->llr == llr);
+    std::size_t errors = 0;
+    for (std::size_t i = 0; i < bits.size(); ++i) errors += std::size_t(__builtin_popcount(unsigned(bits[i] ^ d->hard[i])));
+    CHECK(errors * 50 < bits.size() * 8);                                     // zero forcing at high SNR: nearly every bit comes back
+    // taps alone (scalar weight) and weights alone
+    ofdm::equaliser only_taps{eq->taps, {}, per}, only_w{{}, eq->weights, per};
+    CHECK(orc_demod_c32(n, cp, bps, n_sym, per, reinterpret_cast<const float*>(air.data()), reinterpret_cast<const float*>(taps.data()), nullptr, 1.75f, nullptr,
+                        llr.data(), hard.data()) == 0);
+    auto dt = ofdm::demod_batch<Mod>(air, n, cp, only_taps, 1.75f);
+    CHECK(dt.has_value() && dt->llr == llr && dt->hard == hard);
+    CHECK(orc_demod_c32(n, cp, bps, n_sym, per, reinterpret_cast<const float*>(air.data()), nullptr, wgt.data(), 0.0f, nullptr, llr.data(), hard.data()) == 0);
+    auto dw = ofdm::demod_batch<Mod>(air, n, cp, only_w);
+    CHECK(dw.has_value() && dw->llr == llr && dw->hard == hard);
+    // too few sets for the batch, ragged sets: error values, nothing read out of bounds
+    ofdm::equaliser few{std::vector<std::complex<float>>(taps.begin(), taps.begin() + n), std::vector<float>(wgt.begin(), wgt.begin() + n), per};
+    if (n_sets > 1) { auto bad = ofdm::demod_batch<Mod>(air, n, cp, few); CHECK(!bad.has_value() && bad.error().find("n_sets") != std::string::npos); }
+    ofdm::equaliser ragged{std::vector<std::complex<float>>(n + 1), {}, per};
+    CHECK(!ofdm::demod_batch<Mod>(air, n, cp, ragged).has_value());
+    // an equaliser without arrays is the flat-channel overload
+    auto flat_a = ofdm::demod_batch<Mod>(air, n, cp, ofdm::equaliser{}, 0.5f);
+    auto flat_b = ofdm::demod_batch<Mod>(air, n, cp, 0.5f);
+    CHECK(flat_a.has_value() && flat_b.has_value() && flat_a->llr == flat_b->llr && flat_a->hard == flat_b->hard);
 }
 
 static void streaming_pipe()         // sdrlib/pipe.hpp against demod_batch on the same samples
@@ -204,6 +271,10 @@ int main(int argc, char** argv)
     qam16_hello();
     app_tick();
     extras();
+    equalised_demod<modulation::e64QAM>(1024, 256, 30, 14, 0.0005f);          // the north_star shape: tuned tap-holding kernels
+    equalised_demod<modulation::e16QAM>(64, 16, 9, 4, 0.002f);                // several symbols per wave
+    equalised_demod<modulation::e256QAM>(2048, 512, 5, 2, 0.0002f);
+    equalised_demod<modulation::eQPSK>(256, 33, 7, 3, 0.01f);                 // odd prefix: the generic engines
     streaming_pipe();
     std::printf(g_failed ? "FAILED %d checks\n" : "ok: all drop-in checks passed\n", g_failed);
     return g_failed ? 1 : 0;

@@ -48,6 +48,16 @@ def test_twiddle_tables_equal_oracle(oracle, n, inverse):
     assert np.array_equal(t64, oracle.twiddles(n, bool(inverse), np.complex128))
 
 
+def test_rng_tables_equal_oracle(oracle):
+    """The Gaussian generator's tables (rng.hpp) are built on the host by the library and by the oracle with the same
+    formulas: bit-equal, like the twiddle tables."""
+    from sdr_amd import capi
+    lib = capi.load()
+    t = np.zeros(576, dtype=np.float32)
+    capi.check(lib.sdr_rng_tables_f32(t.ctypes.data_as(ctypes.c_void_p)))
+    assert np.array_equal(t, oracle.rng_tables())
+
+
 def test_non_pow2_error_text():
     from sdr_amd import capi
     lib = capi.load()

@@ -136,3 +136,63 @@ def test_sweep_under_several_ranks_on_one_gpu():
     assert one["checksum_bit_errors"] > 0 and one["total_bits"] >= 6e7
     per_point = _run_sweep(1, ["--per-point"])
     assert per_point["counters"] == one["counters"]
+
+
+def _torchrun_one_rank(script, args, timeout=420):
+    """A fresh child under torch.distributed.run with ONE rank and the default backend: the process joins a
+    process group over RCCL (torch's "nccl") and runs every collective of the multi-GPU path on this GPU."""
+    env = {k: v for k, v in os.environ.items() if k != "SDR_BENCH_BACKEND"}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, script)] + args
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    return json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_sweep_rccl_path_with_one_rank():
+    """The RCCL code path itself -- init_process_group("nccl", device_id=...), the int64 all_reduce(SUM) of the
+    counters, the float64 all_reduce(MAX) of the elapsed time, the barriers -- executed on the one GPU of this
+    box: counters equal those of the plain single-process sweep."""
+    args = ["--bits", "6e7", "--n-fft", "512", "--cp", "128", "--mods", "2", "4", "6", "--step-db", "5"]
+    plain = _run_sweep(1, [])
+    rccl = _torchrun_one_rank("ber_sweep.py", args)
+    pg = rccl["process_group"]
+    assert pg["process_group"] and pg["backend"].startswith("rccl") and pg["world"] == 1
+    assert pg["collectives_run"] >= 5               # two sweeps' all-reduces, barriers, the elapsed-time maximum
+    assert rccl["counters"] == plain["counters"] and rccl["checksum_bit_errors"] == plain["checksum_bit_errors"] > 0
+    assert plain["process_group"]["process_group"] is False
+    assert rccl["fixed_overhead_us"] > 0 and plain["fixed_overhead_us"] > 0
+    assert rccl["gaussian_tail"]["max_sigma"] == 6.66
+
+
+def test_bench_rccl_path_with_one_rank():
+    """bench.py the way the driver starts it for N > 1 (torch.distributed.run, RCCL), with one rank: barrier and
+    max-over-ranks run through the process group, and the line keeps the contract's keys."""
+    line = _torchrun_one_rank("bench.py", ["--gpus", "1", "--steps", "3", "--warmup", "1", "--symbols", "8192", "--no-cpu", "--no-extra"])
+    pg = line["extra"]["process_group"]
+    assert pg["process_group"] and pg["backend"].startswith("rccl") and pg["collectives_run"] >= 3
+    assert line["n_gpus"] == 1 and line["steps"] == 3 and line["value"] > 0 and line["unit"] == "OFDM symbols/s"
+    assert line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"] < 1
+    assert line["per_launch"]["launches"] == 3 and line["per_launch"]["ms_min"] <= line["per_launch"]["ms_median"] <= line["per_launch"]["ms_max"]
+
+
+def test_sweep_zero_flag_and_cached_point_table(ctx):
+    """SDR_SWEEP_ZERO_COUNTERS clears the rows instead of accumulating; a repeated sweep reuses the device copy of its
+    point table and a different one replaces it."""
+    from sdr_amd.link import noise_sigma, llr_weight
+    pts = [(m, noise_sigma(256, m, db), llr_weight(m, db), g0, n) for m, db, g0, n in ((2, 4.0, 0, 30), (6, 12.0, 100, 17), (4, 8.0, 200, 9))]
+    once = ctx.link_sweep(256, 64, 3, pts).cpu().numpy()
+    dirty = torch.full((3, 8), 12345, dtype=torch.int64, device="cuda")
+    assert np.array_equal(ctx.link_sweep(256, 64, 3, pts, dirty, zero_counters=True).cpu().numpy(), once)
+    assert np.array_equal(ctx.link_sweep(256, 64, 3, pts, dirty).cpu().numpy(), 2 * once)              # same table again: accumulates
+    other = [pts[1], pts[0]]
+    swapped = ctx.link_sweep(256, 64, 3, other).cpu().numpy()
+    assert np.array_equal(swapped, once[[1, 0]])
+    assert np.array_equal(ctx.link_sweep(256, 64, 3, pts, dirty, zero_counters=True).cpu().numpy(), once)
+    with pytest.raises(RuntimeError):
+        from sdr_amd import capi
+        import ctypes
+        a = capi.SweepArgs()
+        a.struct_size = ctypes.sizeof(capi.SweepArgs)
+        a.n_fft, a.cp, a.n_points, a.seed, a.flags = 256, 64, 0, 1, 4
+        capi.check(ctx.lib.sdr_link_sweep_c32(ctx._h, ctypes.byref(a)))

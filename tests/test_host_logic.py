@@ -114,3 +114,69 @@ def test_rank_points_rows_line_up_and_tile():
                 pos += n_sym
             assert pos == (p.first_frame + p.n_frames) * SYMBOLS_PER_FRAME
 
+
+
+def _group_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank), "MASTER_ADDR": "127.0.0.1",
+                       "MASTER_PORT": str(port), "SDR_BENCH_BACKEND": "gloo"})
+    import torch
+    from sdr_amd.dist import Group
+    g = Group(torch)
+    t = torch.arange(16, dtype=torch.int64).view(2, 8) * (rank + 1)
+    g.all_reduce_sum_(t)
+    slowest = g.max_over_ranks(1.5 + rank)
+    g.barrier()
+    q.put((rank, t.tolist(), slowest, g.describe()))
+    g.close()
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_process_group_helper_over_gloo(world):
+    """sdr_amd.dist.Group (what bench.py and ber_sweep.py use): a process started with RANK / WORLD_SIZE / MASTER_PORT
+    joins a group and runs the collectives, ALSO when the world is one rank; sums and maxima are what they should be."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_group_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    factor = sum(r + 1 for r in range(world))
+    for rank, t, slowest, desc in got:
+        assert t == [[factor * (8 * i + j) for j in range(8)] for i in range(2)]
+        assert slowest == 1.5 + (world - 1)
+        assert desc["process_group"] is True and desc["backend"] == "gloo" and desc["world"] == world and desc["collectives_run"] == 3
+
+
+def test_no_process_group_without_launcher(monkeypatch):
+    import torch
+    from sdr_amd.dist import Group
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        monkeypatch.delenv(k, raising=False)
+    g = Group(torch)
+    assert not g.active and g.world == 1 and g.rank == 0
+    t = torch.ones(4, dtype=torch.int64)
+    assert g.all_reduce_sum_(t) is t and g.max_over_ranks(2.5) == 2.5
+    g.barrier()
+    assert g.describe()["collectives_run"] == 0
+    g.close()
+
+
+def test_algorithmic_operation_count_model():
+    """ber_sweep.algorithmic_lane_ops_per_symbol: the transform term is 2 x (N/2) log2 N x 10, the count grows with the
+    constellation, the hard-only form needs less, and it stays below what the kernel was measured to execute."""
+    import ber_sweep
+    for n in (64, 1024, 4096):
+        for bps in (1, 2, 4, 6, 8, 10):
+            full, hard = ber_sweep.algorithmic_lane_ops_per_symbol(n, bps), ber_sweep.algorithmic_lane_ops_per_symbol(n, bps, True)
+            assert full > hard > 2 * (n // 2) * (n.bit_length() - 1) * 10
+    for bps, measured in ber_sweep.VALU_LANE_INSTR_PER_SYMBOL_1024.items():
+        assert 0.5 * measured < ber_sweep.algorithmic_lane_ops_per_symbol(1024, bps) < measured

@@ -153,6 +153,35 @@ def test_philox_known_answers(oracle):
         [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
 
 
+def test_gaussian_generator_functions(oracle):
+    """X4 (no reference counterpart): the generator's own ln / sincos / Box-Muller against numpy, its tail bound
+    (32-bit uniform: |z| <= sqrt(64 ln 2) sigma = 6.66 sigma) and its edge words."""
+    us = np.concatenate([2.0 ** -np.arange(0, 33), np.random.default_rng(1).uniform(2.0 ** -32, 1.0, 4000), 1.0 - 2.0 ** -np.arange(1, 25)]).astype(np.float32)
+    got = np.array([oracle.ln_unit(u) for u in us])
+    assert np.abs(got - np.log(us.astype(np.float64))).max() < 4e-6
+    ks = np.concatenate([np.arange(0, 1 << 24, 65536 // 4 + 1), [0, 1, 0x7FFF, 0x8000, 0x8001, 0xFFFFFF, 0xFF8000, 0xFF7FFF]])
+    sc = np.array([oracle.sincos_turn(int(k)) for k in ks])
+    ang = 2 * np.pi * ks / float(1 << 24)
+    assert np.abs(sc[:, 0] - np.sin(ang)).max() < 3e-7 and np.abs(sc[:, 1] - np.cos(ang)).max() < 3e-7
+    # edge words: the largest radius, the zero radius (never NaN)
+    re, im = oracle.gaussian_pair(0, 0)
+    assert abs(np.hypot(re, im) - np.sqrt(64 * np.log(2.0))) < 1e-5 and im == 0.0
+    for x2 in (0, 0x40000000, 0xFFFFFFFF, 0x12345678):
+        re, im = oracle.gaussian_pair(0xFFFFFFFF, x2)
+        assert re == 0.0 and im == 0.0
+        re, im = oracle.gaussian_pair(0xFFFFFF00, x2)
+        assert np.isfinite(re) and np.isfinite(im) and np.hypot(re, im) < 1e-3
+    # moments of 2 x 200000 samples from Philox words
+    rng = np.random.default_rng(2)
+    w = rng.integers(0, 1 << 32, (200000, 2), dtype=np.uint64)
+    z = np.array([oracle.gaussian_pair(int(a), int(b)) for a, b in w]).ravel()
+    assert np.isfinite(z).all() and np.abs(z).max() <= 6.67
+    assert abs(z.mean()) < 0.01 and abs(z.var() - 1.0) < 0.01 and abs((z ** 4).mean() - 3.0) < 0.06
+    t = oracle.rng_tables()
+    assert t.size == 576 and t[64] == 0.0 and t[65] == 1.0
+    assert np.abs(t[1:64:2] + np.log(t[0:64:2].astype(np.float64))).max() < 4e-8      # L_i = fl(-ln r_i): half an ulp of 0.69
+
+
 # ---- extensions: internal consistency -------------------------------------------------------
 @pytest.mark.parametrize("bps", [1, 2, 4, 6, 8, 10])
 def test_constellation_unit_energy_and_roundtrip(oracle, bps):
