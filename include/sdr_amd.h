@@ -127,7 +127,10 @@ int sdr_constellation_f32(int mod, float* norm, float* inorm, float* table);
  *   d_fft   n_sym*n_fft c32: the un-equalised FFT output (= ofdm::rx).
  * d_eq / d_llr_weight hold one set of n_fft taps / weights per `sym_per_set` consecutive
  * symbols (sym_per_set = 0: a single set); NULL d_eq = no equaliser, NULL d_llr_weight = the
- * scalar llr_weight0.  If d_ref_hard (same layout as d_hard) and d_counters are given, the
+ * scalar llr_weight0 -- or, with SDR_DEMOD_WEIGHT_FROM_TAPS in `flags` and taps given, the weight that belongs
+ * to a zero-forcing tap, w_k = llr_weight0 / |G_k|^2 (= norm^2 |H_k|^2 / N0 when llr_weight0 = norm^2 / N0 and
+ * G_k = conj(H_k) / |H_k|^2), formed in the kernel from the tap it already holds: a third fewer tap bytes and half
+ * the tap loads of the two-array form.  If d_ref_hard (same layout as d_hard) and d_counters are given, the
  * kernel also accumulates into d_counters[0..7] (uint64):
  *   [0] bit errors  [1] bits  [2] subcarrier-symbol errors  [3] subcarrier symbols
  *   [4] OFDM symbols  [5] sum trunc(min(|LLR|*1024, 2^30))  [6] LLR sign errors  [7] reserved.
@@ -136,8 +139,9 @@ int sdr_constellation_f32(int mod, float* norm, float* inorm, float* table);
  * any other combination runs the all-outputs instantiation.  n_fft 64..8192 with even cp and
  * 16-byte aligned buffers take the tuned kernels, everything else the generic engines (same
  * results). */
+#define SDR_DEMOD_WEIGHT_FROM_TAPS 1u
 typedef struct sdr_demod_args {
-    uint32_t struct_size;       /* = sizeof(sdr_demod_args) */
+    uint32_t struct_size;       /* = sizeof(sdr_demod_args); the round-2 layout (96 bytes, without `flags`) is accepted as flags = 0 */
     uint32_t n_fft;
     uint32_t cp;
     uint32_t mod;               /* sdr_modulation */
@@ -152,6 +156,8 @@ typedef struct sdr_demod_args {
     void* d_fft;
     const uint8_t* d_ref_hard;
     uint64_t* d_counters;
+    uint32_t flags;             /* 0, or SDR_DEMOD_WEIGHT_FROM_TAPS */
+    uint32_t reserved;          /* 0 */
 } sdr_demod_args;
 int sdr_ofdm_demod_c32(sdr_ctx* ctx, const sdr_demod_args* args);
 /* Same with every pointer in HOST memory (copies in, runs, copies out, synchronises);

@@ -152,7 +152,7 @@ def zf_taps(bps, chan, inv_n0):
     return taps, wgt
 
 
-def demod(rx, n_fft, cp, bps, eq=None, weight=1.0, sym_per_set=0, want_fft=True, want_llr=True, want_hard=True, threads=1):
+def demod(rx, n_fft, cp, bps, eq=None, weight=1.0, sym_per_set=0, want_fft=True, want_llr=True, want_hard=True, threads=1, weight_from_taps=False):
     """Fused receive path on the CPU.  Returns dict(fft, llr, hard).  threads > 1 splits the symbols
     over host threads (same results; the reference itself runs on one)."""
     rx = _c(rx, np.complex64).ravel()
@@ -164,7 +164,7 @@ def demod(rx, n_fft, cp, bps, eq=None, weight=1.0, sym_per_set=0, want_fft=True,
     wt = _c(weight, np.float32).ravel() if isinstance(weight, np.ndarray) else None
     w0 = 0.0 if wt is not None else float(weight)
     rc = lib().orc_demod_c32_threads(ctypes.c_uint(threads), c_uint32(n_fft), c_uint32(cp), c_int(bps), c_size_t(n_sym), c_uint32(sym_per_set),
-                                     _p(rx), _p(eqa), _p(wt), c_float(w0), _p(fft), _p(llr), _p(hard))
+                                     _p(rx), _p(eqa), _p(wt), c_float(w0), _p(fft), _p(llr), _p(hard), ctypes.c_uint(1 if weight_from_taps else 0))
     assert rc == 0, rc
     return {"fft": fft, "llr": llr, "hard": hard}
 

@@ -489,20 +489,23 @@ void generate_symbol(const Constellation& c, std::uint32_t n_fft, std::uint32_t 
 // Receive one symbol: rx (R1), equalise (X1), LLR (X2), nearest (R6/X3).
 void demod_symbol(const Constellation& c, std::uint32_t n_fft, std::uint32_t cp, const float* rx_in,
                   const float* eq /* N c64 or null */, const float* wgt /* N or null */, float w0,
-                  float* fft_out /* N c64 or null */, float* llr_out /* N*bps or null */, unsigned* idx_out /* N or null */)
+                  float* fft_out /* N c64 or null */, float* llr_out /* N*bps or null */, unsigned* idx_out /* N or null */,
+                  bool w_from_taps = false /* no weight array: w_k = w0 / |G_k|^2 (SDR_DEMOD_WEIGHT_FROM_TAPS) */)
 {
     std::vector<float> y(2 * static_cast<std::size_t>(n_fft));
     ofdm_rx<float>(rx_in, static_cast<std::size_t>(n_fft) + cp, cp, y.data());
     if (fft_out) std::memcpy(fft_out, y.data(), y.size() * sizeof(float));
     for (std::uint32_t k = 0; k < n_fft; ++k) {
         float yr = y[2 * k], yi = y[2 * k + 1];
+        float w = wgt ? wgt[k] : w0;
         if (eq) {
             const float gr = eq[2 * k], gi = eq[2 * k + 1];
             const float er = yr * gr - yi * gi;
             const float ei = yr * gi + yi * gr;
             yr = er; yi = ei;
+            if (w_from_taps && !wgt) w = w0 / (gr * gr + gi * gi);
         }
-        if (llr_out) soft_demap_point<float>(c, yr, yi, wgt ? wgt[k] : w0, llr_out + static_cast<std::size_t>(k) * c.bps);
+        if (llr_out) soft_demap_point<float>(c, yr, yi, w, llr_out + static_cast<std::size_t>(k) * c.bps);
         if (idx_out) idx_out[k] = nearest_index<float>(c, yr, yi);
     }
 }
@@ -667,9 +670,9 @@ int orc_zf_taps_f32(int bps, const float* chan, std::size_t n, float inv_n0, flo
 // Fused receive path over a batch (R1 + X1 + X2 + R6/X3).  Set s of the per-subcarrier
 // arrays applies to symbols [s*sym_per_set, (s+1)*sym_per_set); sym_per_set = 0 means one set.
 // hard_out receives floor(n_sym*N*bps/8) bytes, MSB first over the whole batch.
-int orc_demod_c32(std::uint32_t n_fft, std::uint32_t cp, int bps, std::size_t n_sym, std::uint32_t sym_per_set,
-                  const float* rx, const float* eq, const float* wgt, float w0,
-                  float* fft_out, float* llr_out, std::uint8_t* hard_out)
+int orc_demod_flags_c32(std::uint32_t n_fft, std::uint32_t cp, int bps, std::size_t n_sym, std::uint32_t sym_per_set,
+                        const float* rx, const float* eq, const float* wgt, float w0,
+                        float* fft_out, float* llr_out, std::uint8_t* hard_out, unsigned flags /* 1: weights from the taps */)
 {
     Constellation c;
     if (!make_constellation(bps, c)) return 1;
@@ -683,7 +686,7 @@ int orc_demod_c32(std::uint32_t n_fft, std::uint32_t cp, int bps, std::size_t n_
                      eq ? eq + 2 * set * n_fft : nullptr, wgt ? wgt + set * n_fft : nullptr, w0,
                      fft_out ? fft_out + 2 * s * n_fft : nullptr,
                      llr_out ? llr_out + s * n_fft * bps : nullptr,
-                     hard_out ? idx.data() : nullptr);
+                     hard_out ? idx.data() : nullptr, (flags & 1u) != 0);
         if (hard_out)
             for (std::uint32_t k = 0; k < n_fft; ++k) {
                 const std::size_t pos = (s * n_fft + k) * static_cast<std::size_t>(bps);
@@ -693,15 +696,22 @@ int orc_demod_c32(std::uint32_t n_fft, std::uint32_t cp, int bps, std::size_t n_
     return 0;
 }
 
+int orc_demod_c32(std::uint32_t n_fft, std::uint32_t cp, int bps, std::size_t n_sym, std::uint32_t sym_per_set,
+                  const float* rx, const float* eq, const float* wgt, float w0,
+                  float* fft_out, float* llr_out, std::uint8_t* hard_out)
+{
+    return orc_demod_flags_c32(n_fft, cp, bps, n_sym, sym_per_set, rx, eq, wgt, w0, fft_out, llr_out, hard_out, 0u);
+}
+
 // The same over n_threads host threads, symbols split into contiguous ranges (symbols are
 // independent, lib/inc/ofdm.hpp:37-43 keeps no state; SURVEY.md 8(d) CPU baseline (ii)).  The
 // reference itself is single-threaded (its OpenMP pragma, fft.hpp:119, is dead).  Needs
 // n_fft*bps to be a whole number of bytes so that the ranges' hard bits do not share a byte.
 int orc_demod_c32_threads(unsigned n_threads, std::uint32_t n_fft, std::uint32_t cp, int bps, std::size_t n_sym, std::uint32_t sym_per_set,
                           const float* rx, const float* eq, const float* wgt, float w0,
-                          float* fft_out, float* llr_out, std::uint8_t* hard_out)
+                          float* fft_out, float* llr_out, std::uint8_t* hard_out, unsigned flags)
 {
-    if (n_threads <= 1 || n_sym < 2 * n_threads) return orc_demod_c32(n_fft, cp, bps, n_sym, sym_per_set, rx, eq, wgt, w0, fft_out, llr_out, hard_out);
+    if (n_threads <= 1 || n_sym < 2 * n_threads) return orc_demod_flags_c32(n_fft, cp, bps, n_sym, sym_per_set, rx, eq, wgt, w0, fft_out, llr_out, hard_out, flags);
     const std::size_t sym_bits = static_cast<std::size_t>(n_fft) * static_cast<std::size_t>(bps);
     if (sym_bits % 8 != 0) return 1;
     const std::size_t unit = sym_per_set ? sym_per_set : 1;          // ranges start on a set boundary
@@ -714,12 +724,12 @@ int orc_demod_c32_threads(unsigned n_threads, std::uint32_t n_fft, std::uint32_t
         if (first >= last) continue;
         pool.emplace_back([=, &rc] {
             const std::size_t set0 = sym_per_set ? first / sym_per_set : 0;
-            rc[t] = orc_demod_c32(n_fft, cp, bps, last - first, sym_per_set,
+            rc[t] = orc_demod_flags_c32(n_fft, cp, bps, last - first, sym_per_set,
                                   rx + 2 * first * (static_cast<std::size_t>(n_fft) + cp),
                                   eq ? eq + 2 * set0 * n_fft : nullptr, wgt ? wgt + set0 * n_fft : nullptr, w0,
                                   fft_out ? fft_out + 2 * first * n_fft : nullptr,
                                   llr_out ? llr_out + first * sym_bits : nullptr,
-                                  hard_out ? hard_out + first * sym_bits / 8 : nullptr);
+                                  hard_out ? hard_out + first * sym_bits / 8 : nullptr, flags);
         });
     }
     for (auto& th : pool) th.join();

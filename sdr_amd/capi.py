@@ -46,6 +46,8 @@ class DemodArgs(Structure):
         ("d_fft", c_void_p),
         ("d_ref_hard", c_void_p),
         ("d_counters", c_void_p),
+        ("flags", c_uint32),
+        ("reserved", c_uint32),
     ]
 
 
@@ -70,6 +72,7 @@ class LinkArgs(Structure):
 
 
 POINT_HARD_ONLY = 1     # sdr_sweep_point.flags: hard decisions only, counters 5 and 6 untouched
+DEMOD_WEIGHT_FROM_TAPS = 1  # sdr_demod_args.flags: w_k = llr_weight0 / |G_k|^2 from the taps, no weight array
 SWEEP_ZERO_COUNTERS = 1     # sdr_sweep_args.flags: the call clears the counters ahead of the launch
 
 

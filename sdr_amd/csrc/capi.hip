@@ -7,6 +7,8 @@
 #include "rng.hpp"
 
 #include <cmath>
+#include <cstddef>
+#include <cstring>
 
 using namespace sdr;
 
@@ -55,6 +57,30 @@ int ofdm_tx_device(sdr_ctx* ctx, bool is_double, const void* d_in, size_t n_fft,
     return is_double ? fft_generic_f64(ctx, d_in, d_out, n_fft, true, n_fft, 0, n_fft + cp, cp, cp, n_sym)
                      : fft_generic_f32(ctx, d_in, d_out, n_fft, true, n_fft, 0, n_fft + cp, cp, cp, n_sym);
 }
+
+} // namespace
+
+namespace sdr {
+
+int read_demod_args(const sdr_demod_args* in, sdr_demod_args& out)
+{
+    if (!in) return fail(SDR_ERR_INVALID, "null args");
+    constexpr size_t kLegacy = offsetof(sdr_demod_args, flags);      // the round-2 layout ends where `flags` begins
+    out = sdr_demod_args{};
+    if (in->struct_size == sizeof(sdr_demod_args)) out = *in;
+    else if (in->struct_size == kLegacy) memcpy(&out, in, kLegacy);
+    else return fail(SDR_ERR_INVALID, "sdr_demod_args.struct_size %u != %zu", in->struct_size, sizeof(sdr_demod_args));
+    out.struct_size = sizeof(sdr_demod_args);
+    if (out.flags & ~static_cast<uint32_t>(SDR_DEMOD_WEIGHT_FROM_TAPS)) return fail(SDR_ERR_INVALID, "sdr_demod_args: unknown flags 0x%x", out.flags);
+    if ((out.flags & SDR_DEMOD_WEIGHT_FROM_TAPS) && (!out.d_eq || out.d_llr_weight))
+        return fail(SDR_ERR_INVALID, "SDR_DEMOD_WEIGHT_FROM_TAPS needs d_eq and no d_llr_weight");
+    if (!valid_mod(static_cast<int>(out.mod))) return fail(SDR_ERR_INVALID, "unknown modulation %u", out.mod);
+    return SDR_OK;
+}
+
+} // namespace sdr
+
+namespace {
 
 // copy in -> run -> copy out -> synchronise
 template <typename Fn>
@@ -206,10 +232,8 @@ int sdr_constellation_f32(int mod, float* norm, float* inorm, float* table)
 int sdr_ofdm_demod_c32(sdr_ctx* ctx, const sdr_demod_args* args)
 {
     SDR_TRY(ensure_device(ctx));
-    if (!args) return fail(SDR_ERR_INVALID, "null args");
-    if (args->struct_size != sizeof(sdr_demod_args)) return fail(SDR_ERR_INVALID, "sdr_demod_args.struct_size %u != %zu", args->struct_size, sizeof(sdr_demod_args));
-    const sdr_demod_args& a = *args;
-    if (!valid_mod(static_cast<int>(a.mod))) return fail(SDR_ERR_INVALID, "unknown modulation %u", a.mod);
+    sdr_demod_args a;
+    SDR_TRY(read_demod_args(args, a));
     if (a.n_sym == 0 || a.n_fft == 0) return SDR_OK;
     if (!is_pow2(a.n_fft)) return fail(SDR_ERR_NOT_POW2, "%s", kPow2Message);
     if (!a.d_rx) return fail(SDR_ERR_INVALID, "null d_rx");
@@ -286,10 +310,9 @@ int sdr_soft_demap_host_c32(sdr_ctx* ctx, int mod, const void* h_sym, size_t n_s
 int sdr_ofdm_demod_host_c32(sdr_ctx* ctx, const sdr_demod_args* host_args, size_t n_sets)
 {
     SDR_TRY(ensure_device(ctx));
-    if (!host_args) return fail(SDR_ERR_INVALID, "null args");
-    if (host_args->struct_size != sizeof(sdr_demod_args)) return fail(SDR_ERR_INVALID, "sdr_demod_args.struct_size mismatch");
-    sdr_demod_args a = *host_args;
-    if (!valid_mod(static_cast<int>(a.mod))) return fail(SDR_ERR_INVALID, "unknown modulation %u", a.mod);
+    sdr_demod_args a;
+    SDR_TRY(read_demod_args(host_args, a));
+    const sdr_demod_args given = a;      // the caller's host pointers
     if (a.n_sym == 0 || a.n_fft == 0) return SDR_OK;
     if (!is_pow2(a.n_fft)) return fail(SDR_ERR_NOT_POW2, "%s", kPow2Message);
     if (!a.d_rx) return fail(SDR_ERR_INVALID, "null rx");
@@ -329,10 +352,10 @@ int sdr_ofdm_demod_host_c32(sdr_ctx* ctx, const sdr_demod_args* host_args, size_
     if (a.d_hard) a.d_hard = static_cast<uint8_t*>(hard.p);
     if (a.d_fft) a.d_fft = fft.p;
     SDR_TRY(sdr_ofdm_demod_c32(ctx, &a));
-    if (host_args->d_llr) SDR_HIP(hipMemcpyAsync(host_args->d_llr, llr.p, bins * a.mod * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (host_args->d_hard) SDR_HIP(hipMemcpyAsync(host_args->d_hard, hard.p, hard_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    if (host_args->d_fft) SDR_HIP(hipMemcpyAsync(host_args->d_fft, fft.p, bins * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (host_args->d_counters) SDR_HIP(hipMemcpyAsync(host_args->d_counters, cnt.p, 64, hipMemcpyDeviceToHost, ctx->stream));
+    if (given.d_llr) SDR_HIP(hipMemcpyAsync(given.d_llr, llr.p, bins * a.mod * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (given.d_hard) SDR_HIP(hipMemcpyAsync(given.d_hard, hard.p, hard_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (given.d_fft) SDR_HIP(hipMemcpyAsync(given.d_fft, fft.p, bins * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (given.d_counters) SDR_HIP(hipMemcpyAsync(given.d_counters, cnt.p, 64, hipMemcpyDeviceToHost, ctx->stream));
     SDR_HIP(hipStreamSynchronize(ctx->stream));
     return SDR_OK;
 }

@@ -312,7 +312,7 @@ __device__ inline unsigned long long wave_sum(unsigned long long v)
 // Generic-size back end of the fused path: one thread per subcarrier of the whole batch.
 template <int MI, int MQ>
 __global__ void demap_fft_kernel(const float2* __restrict__ fft, uint32_t n_fft, uint64_t n_sym, uint32_t sym_per_set,
-                                 const float2* __restrict__ eq, const float* __restrict__ wgt, float w0, float inorm,
+                                 const float2* __restrict__ eq, const float* __restrict__ wgt, float w0, bool w_from_taps, float inorm,
                                  float* __restrict__ llr, uint16_t* __restrict__ index,
                                  const uint8_t* __restrict__ ref_bits, unsigned long long* __restrict__ counters)
 {
@@ -324,13 +324,14 @@ __global__ void demap_fft_kernel(const float2* __restrict__ fft, uint32_t n_fft,
         const uint32_t k = static_cast<uint32_t>(e - s * n_fft);
         const size_t set = sym_per_set ? s / sym_per_set : 0;
         float2 y = fft[e];
+        float w = wgt ? wgt[set * n_fft + k] : w0;
         if (eq) {
             const float2 g = eq[set * n_fft + k];
             const float er = y.x * g.x - y.y * g.y;
             const float ei = y.x * g.y + y.y * g.x;
             y.x = er; y.y = ei;
+            if (w_from_taps) w = w0 / (g.x * g.x + g.y * g.y);      // SDR_DEMOD_WEIGHT_FROM_TAPS (no weight array)
         }
-        const float w = wgt ? wgt[set * n_fft + k] : w0;
         float l[BPS];
         const unsigned idx = demap_point<float, MI, MQ, true, true>(y.x, y.y, inorm, w, l);
         if (llr) {
@@ -470,7 +471,8 @@ int demap_after_fft(sdr_ctx* ctx, const sdr_demod_args& a, const void* d_fft)
     const int mod = static_cast<int>(a.mod);
     dispatch_mod(mod, [&]<int MI, int MQ>() {
         hipLaunchKernelGGL((demap_fft_kernel<MI, MQ>), dim3(grid), dim3(kThreads), 0, ctx->stream, static_cast<const float2*>(d_fft), a.n_fft, a.n_sym,
-                           a.sym_per_set, static_cast<const float2*>(a.d_eq), a.d_llr_weight, a.llr_weight0, inorm_in<float>(mod), a.d_llr,
+                           a.sym_per_set, static_cast<const float2*>(a.d_eq), a.d_llr_weight, a.llr_weight0,
+                           (a.flags & SDR_DEMOD_WEIGHT_FROM_TAPS) != 0 && a.d_eq && !a.d_llr_weight, inorm_in<float>(mod), a.d_llr,
                            static_cast<uint16_t*>(idx), a.d_ref_hard, want_counters ? reinterpret_cast<unsigned long long*>(a.d_counters) : nullptr);
     });
     SDR_HIP(hipGetLastError());

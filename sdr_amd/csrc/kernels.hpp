@@ -20,7 +20,11 @@ int zf_taps_dev(sdr_ctx* ctx, int mod, const void* d_chan, size_t n, float inv_n
 // equalise + LLR + hard + counters on FFT outputs already in memory (generic sizes of the fused path)
 int demap_after_fft(sdr_ctx* ctx, const sdr_demod_args& a, const void* d_fft);
 
-// rx_fused.hip: the tuned fused receive kernel (fp32, n_fft 64..4096).
+// capi.hip: copies the caller's sdr_demod_args (current layout, or the 96-byte round-2 layout without `flags`) and checks
+// what every receive entry point checks first
+int read_demod_args(const sdr_demod_args* in, sdr_demod_args& out);
+
+// rx_fused.hip: the tuned fused receive kernel (fp32, n_fft 64..8192).
 bool rx_fused_supported(uint32_t n_fft, uint32_t mod);
 bool rx_fused_layout_ok(const sdr_demod_args& a);
 // Device memory the launch needs beyond inputs and outputs.  Null members are taken from the

@@ -122,10 +122,8 @@ using namespace sdr;
 extern "C" int sdr_ofdm_demod_noalloc_c32(sdr_ctx* ctx, const sdr_demod_args* args)
 {
     SDR_TRY(ensure_device(ctx));
-    if (!args) return fail(SDR_ERR_INVALID, "null args");
-    if (args->struct_size != sizeof(sdr_demod_args)) return fail(SDR_ERR_INVALID, "sdr_demod_args.struct_size %u != %zu", args->struct_size, sizeof(sdr_demod_args));
-    const sdr_demod_args& a = *args;
-    if (!valid_mod(static_cast<int>(a.mod))) return fail(SDR_ERR_INVALID, "unknown modulation %u", a.mod);
+    sdr_demod_args a;
+    SDR_TRY(read_demod_args(args, a));
     if (a.n_sym == 0 || a.n_fft == 0) return SDR_OK;
     if (!is_pow2(a.n_fft)) return fail(SDR_ERR_NOT_POW2, "%s", kPow2Message);
     if (!a.d_rx) return fail(SDR_ERR_INVALID, "null d_rx");

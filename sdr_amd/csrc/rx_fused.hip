@@ -96,16 +96,12 @@ int rx_fused_launch(sdr_ctx* ctx, const sdr_demod_args& a, const RxWorkspace* ws
     p.cp = a.cp;
     p.sym_per_set = a.sym_per_set;
     p.w0 = a.llr_weight0;
+    p.w_from_taps = (a.flags & SDR_DEMOD_WEIGHT_FROM_TAPS) && a.d_eq && !a.d_llr_weight;
     p.inorm = std::sqrt(static_cast<float>(grid_energy(static_cast<int>(a.mod))));
     const bool full = a.d_hard || a.d_fft || a.d_counters || !a.d_llr;
     const bool hard_only = a.d_hard && !a.d_llr && !a.d_fft && !a.d_counters && !a.d_eq && a.mod != 1;   // weights do not matter to nearest()
     int variant = hard_only ? 4 : (full ? 2 : 0) | ((a.d_eq || a.d_llr_weight) ? 1 : 0);
-#ifdef SDR_GROUP_VARIANTS
-    // Experiment (profiles/r2_eq_grouped_taps.txt: no gain, off in the shipped build): SDR_GROUP=7 / 2
-    // symbols of one tap set per workgroup share the set's taps through LDS (RxShape GROUP).
-    static const int group = [] { const char* v = getenv("SDR_GROUP"); return v ? atoi(v) : 0; }();
-    if (variant == 1 && (group == 7 || group == 2) && a.n_fft == 1024 && a.sym_per_set != 0 && a.sym_per_set % group == 0 && aligned(a.d_llr_weight, 16)) variant = group == 2 ? 6 : 5;
-#endif
+    if (variant == 1 && !a.d_llr_weight) variant = 9;      // LLRs only, taps without a weight array: no weight loads at all
     SDR_TRY(dispatch(ctx, ilog2(a.n_fft), p, static_cast<int>(a.mod), variant));
     if (a.d_counters) SDR_TRY(fold_counter_slots(ctx, p.counters, reinterpret_cast<unsigned long long*>(a.d_counters), a.n_sym * a.n_fft, a.mod, a.n_sym));
     return SDR_OK;

@@ -24,16 +24,11 @@
 // Instantiations <LOG2N, MI, MQ, FULL, EQ, HARDONLY>: MI/MQ = bits on the I/Q axis (0,0 = FFT
 // only); FULL = hard bits / bins / counters optional at run time; EQ = per-subcarrier taps / weights
 // held in registers; HARDONLY = packed hard decisions as the only output.  RxShape holds each
-// instantiation's LDS layout, control structure and waves-per-SIMD bounds.
-// Compile-time experiment switches kept for A/B measurements (DESIGN.md sections 6.1 and 7 give the
-// numbers): SDR_WPE=<n> (force waves per SIMD), SDR_EQ_WPE, SDR_NO_MAX_WAVES (no even-spread cap),
-// SDR_LATE_TAPS / SDR_LATE_TAPS_FULL / SDR_LATE_AT (taps per symbol instead of held), SDR_EQ_SET0,
-// SDR_NT_LOADS (non-temporal sample loads), SDR_PLAIN_STORES (LLR stores without the non-temporal
-// hint), SDR_NO_STAGE8 / SDR_NO_STG_ALIAS / SDR_ALIAS_FROM / SDR_NO_SMALL_STAGE (LLR staging
-// variants), SDR_EQ_FORM_ALL / SDR_EQ_FORM_13 / SDR_LATE_AT_13 / SDR_EPI_AHEAD / SDR_EQ_RUN / SDR_EPILOGUE_TAPS_FULL_FROM
-// (how and when the taps are fetched), SDR_FULL_IDX_ALIAS_FROM (hard decisions and reference bits in the exchange
-// region), SDR_STG_PAIRS / SDR_BINS_STAGED (line-sized stores at N = 64), SDR_TW_PARK_LATE (twiddle table set-up).
-// Run-time knobs: see RxTuning.
+// instantiation's LDS layout, control structure and waves-per-SIMD bounds; its per-shape rules were
+// each adopted from same-buffer A/Bs of two builds (tools/abbench.py; numbers in profiles/r2_*.txt and
+// DESIGN.md section 6.1).  The compile-time experiment switches of rounds 1-2 that lost or measured
+// level (shared taps through LDS, non-temporal tap loads, plain LLR stores, taps per symbol at N = 8192,
+// ...) were removed in round 3; their results stay in profiles/.  Run-time knobs: see RxTuning.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -64,6 +59,7 @@ struct RxParams {
     uint32_t sym_per_set;
     float w0;
     float inorm;
+    uint32_t w_from_taps;        // no weight array: w_k = w0 / |G_k|^2 instead of the scalar w0 (SDR_DEMOD_WEIGHT_FROM_TAPS)
     uint32_t groups_per_wg;      // consecutive symbol groups handled by one workgroup
     uint32_t xcd_window;         // workgroup-id permutation window (multiple of 8; 0 = none)
 };
@@ -312,22 +308,17 @@ struct NoLateWork { __device__ __forceinline__ void operator()() const {} };
 // `late` runs between the two barriers of the second exchange (3-pass plans): the place where
 // kernels that are short of registers request what only the last pass and the epilogue need
 // (last-pass twiddles, equaliser taps), so that it is not live across the first two passes.
-// WAVE_SYNC: the symbol lives in ONE wave of a workgroup that holds several symbols (RxShape GROUP):
-// its exchanges need program order inside the wave only (LDS serves a wave's instructions in order),
-// not a barrier over the other symbols' waves.
-template <bool WAVE_SYNC>
-__device__ __forceinline__ void symbol_sync()
+// Data exchanged through LDS inside ONE wave needs program order only (LDS serves a wave's instructions in
+// order), not a workgroup barrier: the fences keep the compiler from moving the reads above the stores
+// (the bare wave barrier intrinsic carries no memory semantics).
+__device__ __forceinline__ void wave_lds_sync()
 {
-    if constexpr (WAVE_SYNC) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    } else {
-        __syncthreads();
-    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int LOG2N, bool CONJ = false, typename Late = NoLateWork, int LATE_AT = 1, bool WAVE_SYNC = false>
+template <int LOG2N, bool CONJ = false, typename Late = NoLateWork, int LATE_AT = 1>
 __device__ __forceinline__ void fft_run(float2 (&x)[PlanOps<LOG2N>::kE], unsigned char* lds_data, const FftAddr<LOG2N>& a, const FftTwiddles<LOG2N>& w, Late&& late = Late{})
 {
     using O = PlanOps<LOG2N>;
@@ -344,7 +335,7 @@ __device__ __forceinline__ void fft_run(float2 (&x)[PlanOps<LOG2N>::kE], unsigne
     });
     static_for<E>([&](auto M) { constexpr int m = M; *reinterpret_cast<float2*>(lds_data + a.wr0 + O::reg_addr(0, 0, m)) = x[m]; });
     if constexpr (LATE_AT == 0) late();
-    symbol_sync<WAVE_SYNC>();
+    __syncthreads();
     static_for<E>([&](auto M) { constexpr int m = M; x[m] = *reinterpret_cast<const float2*>(lds_data + a.rd0 + O::reg_addr(0, 1, m)); });
     if constexpr (O::kPasses == 3) {
         static_for<P::kR[1]>([&](auto S) {
@@ -356,10 +347,10 @@ __device__ __forceinline__ void fft_run(float2 (&x)[PlanOps<LOG2N>::kE], unsigne
                 bfly<CONJ>(x[m0], x[m1], w.mid[(1 << c) - 1 - O::kMidFirst + jm + a.mid_jt]);
             });
         });
-        symbol_sync<WAVE_SYNC>();   // all reads of exchange 0 done before the region is rewritten
+        __syncthreads();   // all reads of exchange 0 done before the region is rewritten
         if constexpr (LATE_AT == 1) late();
         static_for<E>([&](auto M) { constexpr int m = M; *reinterpret_cast<float2*>(lds_data + a.wr1 + O::reg_addr(1, 1, m)) = x[m]; });
-        symbol_sync<WAVE_SYNC>();
+        __syncthreads();
         static_for<E>([&](auto M) { constexpr int m = M; x[m] = *reinterpret_cast<const float2*>(lds_data + a.rd1 + O::reg_addr(1, 2, m)); });
     }
     if constexpr (LATE_AT == 2) late();      // behind the last exchange read: nothing but the last butterflies left to cover it
@@ -384,11 +375,7 @@ typedef float sdr_v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void stream_store4(float* dst, float a, float b, float c, float d)
 {
     sdr_v4f v = {a, b, c, d};
-#ifdef SDR_PLAIN_STORES
-    *reinterpret_cast<sdr_v4f*>(dst) = v;
-#else
     __builtin_nontemporal_store(v, reinterpret_cast<sdr_v4f*>(dst));
-#endif
 }
 __device__ __forceinline__ void stream_store2(float* dst, float a, float b)
 {
@@ -398,11 +385,7 @@ __device__ __forceinline__ void stream_store2(float* dst, float a, float b)
 
 // LLR staging through LDS: per-lane chunk of C floats -> lane-contiguous vectors (coalesced stores)
 constexpr int stage_stride_bytes(int c) { return c == 6 ? 24 : c == 8 ? 48 : c == 12 ? 48 : c == 16 ? 80 : c == 20 ? 80 : c * 4; }
-#ifdef SDR_NO_STAGE8
-constexpr bool stage_wanted(int c) { return c == 6 || c == 12 || c == 16; }
-#else
 constexpr bool stage_wanted(int c) { return c == 6 || c == 8 || c == 10 || c == 12 || c == 16 || c == 20; }
-#endif
 
 __device__ __forceinline__ unsigned ref_bits(const uint8_t* __restrict__ s, size_t pos, int nbits)
 {
@@ -420,99 +403,32 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
     return v;
 }
 
-#ifndef SDR_LINEAR_STRIP
-#define SDR_LINEAR_STRIP 1
-#endif
-#ifndef SDR_LATE_AT
-#define SDR_LATE_AT 0
-#endif
-#ifndef SDR_LATE_TAPS_FULL
-#define SDR_LATE_TAPS_FULL 0
-#endif
-#ifndef SDR_EQ_FORM_BPSK
-#define SDR_EQ_FORM_BPSK 0
-#endif
-#ifndef SDR_NT_EQ
-#define SDR_NT_EQ -1     // -1: per-size rule, 0: never, 1: every tap-reading variant
-#endif
-#ifndef SDR_EQ_FORM_12_10
-#define SDR_EQ_FORM_12_10 0
-#endif
-#ifndef SDR_LATE_13
-#define SDR_LATE_13 0
-#endif
-#ifndef SDR_EQ_FORM_13
-#define SDR_EQ_FORM_13 3
-#endif
-#ifndef SDR_LATE_AT_13
-#define SDR_LATE_AT_13 2
-#endif
-#ifndef SDR_TW_PARK_LATE
-#define SDR_TW_PARK_LATE 0      // 1: the LDS twiddle table is written behind the request for the first symbol's samples -- same-buffer A/B: -1.8 to -6.1 points at N = 1024 ... 4096 (level elsewhere), so the set-up keeps its own wait
-#endif
-#ifndef SDR_EPI_AHEAD
-#define SDR_EPI_AHEAD 4      // same-buffer A/B at N = 8192: BPSK 32.4 -> 49.3 %, QPSK 42.7 -> 56.6, 16-QAM 50.3 -> 60.0, the others +0.2 to +1.0 (8: level, 1024-QAM -1.6)
-#endif
-#ifndef SDR_LATE_13_WPE
-#define SDR_LATE_13_WPE 2
-#endif
-#ifndef SDR_LATE_FROM
-#define SDR_LATE_FROM 11
-#endif
-#ifndef SDR_LATE_WPE
-#define SDR_LATE_WPE 3
-#endif
-#ifndef SDR_LATE_TAPS
-#define SDR_LATE_TAPS -1     // -1: per-shape rule (RxShape::LATE_TAPS), 0: never, 1: N = 2^SDR_LATE_FROM ... 4096
-#endif
-#ifndef SDR_EQ_WPE
-#define SDR_EQ_WPE 2
-#endif
-#ifndef SDR_EQ_FORCE_LOOP
-#define SDR_EQ_FORCE_LOOP 0      // 1: experiment, every tap-holding variant takes the run of two again
-#endif
-#ifndef SDR_EQ_NOLOOP
-#define SDR_EQ_NOLOOP 0
-#endif
-#ifndef SDR_ALIAS_FROM
-#define SDR_ALIAS_FROM 13
-#endif
-
 // Compile-time shape of one instantiation: LDS layout, control structure and the bounds on the
 // waves per SIMD handed to the compiler.
-// GROUP > 1 (tap-holding LLR-only variant at N = 1024 / 2048): the workgroup is GROUP independent
-// symbols, each run by its own kWG threads exactly like a one-symbol workgroup, that belong to ONE
-// tap set (the host picks this variant when sym_per_set is a multiple of GROUP) and share its taps and
-// weights through LDS.  The taps then cross L2 -> CU once per GROUP symbols as two loads per thread,
-// instead of once per two symbols as sixteen loads per thread into 48 held registers: that path, not
-// the arithmetic, is what the tap-holding variant loses against the plain one.
-template <int LOG2N, int MI, int MQ, bool FULL, bool EQ, bool HARDONLY, int GROUP = 1>
+// NOWGT (EQ, LLR only): taps without a weight array -- the weight is the scalar w0 or is derived from the tap
+// (RxParams::w_from_taps); no weight load is issued at all (the other EQ instantiations read a dummy source
+// when an array is missing, to keep their loads unconditional).
+template <int LOG2N, int MI, int MQ, bool FULL, bool EQ, bool HARDONLY, bool NOWGT = false>
 struct RxShape {
     using O = PlanOps<LOG2N>;
     static constexpr int N = O::kN, SPW = O::kSPW;
     static constexpr int BPS = MI + MQ;
     static constexpr bool DEMAP = BPS > 0;
     static_assert(!(HARDONLY && (FULL || EQ || !DEMAP)), "HARDONLY is a variant of its own");
-    static_assert(GROUP == 1 || (EQ && !FULL && !HARDONLY && DEMAP && O::kSPW == 1 && O::kWG * GROUP <= 1024), "grouped symbols: tap-holding LLR-only variant, one symbol per kWG threads");
-    static constexpr int WG_THREADS = O::kWG * GROUP;
+    static_assert(!NOWGT || (EQ && !FULL && DEMAP), "taps without a weight array: a form of the LLR-only tap-reading variant");
+    static constexpr int WG_THREADS = O::kWG;
     static constexpr int SYM_BYTES = O::max_sym_bytes();
-    static constexpr int DATA_BYTES = SYM_BYTES * SPW * GROUP;
+    static constexpr int DATA_BYTES = SYM_BYTES * SPW;
     static constexpr int TW_BYTES = O::kMidCount * 8;
     using idx_t = std::conditional_t<(BPS > 8), uint16_t, uint8_t>;      // one hard decision
     static constexpr bool HARD_PATH = (FULL || HARDONLY) && DEMAP;       // hard decisions pass through LDS and are packed
     // Hard-only kernels park their decisions in the exchange region, dead after the transform's last
     // exchange read (multi-wave workgroups pay one barrier for it): 10.2 -> 8.2 KiB at N = 1024.
-#ifndef SDR_HARD_IDX_ALIAS
-#define SDR_HARD_IDX_ALIAS 1
-#endif
-    // The every-output variants do the same from SDR_FULL_IDX_ALIAS_FROM on and at 1024-QAM (behind the staging strips,
+    // The every-output variants do the same from N = 4096 on and at 1024-QAM (behind the staging strips,
     // which alias the region too): at N = 8192 it is the difference between one and two workgroups per CU (+12.5 to
     // +19.7 points), at N = 4096 +1.9 to +3.2, at 1024-QAM +1.5 to +3.3; the other shapes are level or lose the
     // price of the extra barrier (-0.4 to -1.9; same-buffer A/Bs, tools/abbench.py).
-#ifndef SDR_FULL_IDX_ALIAS_FROM
-#define SDR_FULL_IDX_ALIAS_FROM 12
-#endif
-    static constexpr bool IDX_ALIAS = HARD_PATH && SDR_HARD_IDX_ALIAS && (HARDONLY || (FULL && (LOG2N >= SDR_FULL_IDX_ALIAS_FROM || BPS == 10)));
+    static constexpr bool IDX_ALIAS = HARD_PATH && (HARDONLY || (FULL && (LOG2N >= 12 || BPS == 10)));
     static constexpr int IDX_RAW_BYTES = HARD_PATH ? N * SPW * static_cast<int>(sizeof(idx_t)) : 0;
     static constexpr int IDX_BYTES = IDX_ALIAS ? 0 : IDX_RAW_BYTES;
     // ... and park the reference bits there as well, written behind the last exchange read instead of ahead of the transform
@@ -525,32 +441,19 @@ struct RxShape {
     // Several symbols per wave (N <= 256): one output block is a run of TPS * CHUNK floats per symbol.  Where that
     // run is not a whole number of 128-byte lines (N = 64 at QPSK / 64-QAM / 1024-QAM: 64 / 192 / 320 bytes) two
     // (BPSK: four) consecutive blocks are staged together, so that every store covers whole lines (128 / 384 / 640 bytes per symbol).
-#ifndef SDR_STG_PAIRS
-#define SDR_STG_PAIRS 1
-#endif
-#ifndef SDR_STG_LINE4
-#define SDR_STG_LINE4 256
-#endif
-#ifndef SDR_STG_LINE
-#define SDR_STG_LINE 128      // bytes a staged run must be a multiple of
-#endif
-#ifndef SDR_BINS_STAGED
-#define SDR_BINS_STAGED 1
-#endif
+    // 16-QAM at N = 64 (one line per block, stored per lane) and QPSK / 1024-QAM at N = 256 take 256-byte runs:
+    // +3.9 / +1.8 / +2.2 (with taps +2.3); 256-byte runs are level or worse for the other shapes.
     static constexpr int RUN_BYTES = O::kTPS * CHUNK * 4;
     static constexpr int stg_blocks()
     {
-        if (!(SDR_STG_PAIRS && DEMAP && !HARDONLY && SPW > 1 && O::kWG == 64 && GROUP == 1 && stage_stride_bytes(CHUNK) == CHUNK * 4)) return 1;
+        if (!(DEMAP && !HARDONLY && SPW > 1 && O::kWG == 64 && stage_stride_bytes(CHUNK) == CHUNK * 4)) return 1;
+        const int line = (CHUNK == 4 || (LOG2N == 8 && (BPS == 2 || BPS == 10))) ? 256 : 128;      // bytes a staged run must be a multiple of
         for (int nb = 1; nb <= 4; nb *= 2)
-            if ((nb * RUN_BYTES) % ((CHUNK == 4 || (LOG2N == 8 && (BPS == 2 || BPS == 10))) ? SDR_STG_LINE4 : SDR_STG_LINE) == 0 && (O::kE / O::kGroupOut) % nb == 0) return nb;      // 16-QAM at N = 64 (one line per block, stored per lane): +3.9 staged in pairs; N = 256 QPSK / 1024-QAM: +1.8 / +2.2 (with taps +2.3); 256-byte runs are level or worse for the others
+            if ((nb * RUN_BYTES) % line == 0 && (O::kE / O::kGroupOut) % nb == 0) return nb;
         return 1;
     }
     static constexpr int STG_BLOCKS = stg_blocks();
-#ifdef SDR_NO_SMALL_STAGE
-    static constexpr bool STAGE = DEMAP && !HARDONLY && SPW == 1 && stage_wanted(CHUNK);
-#else
     static constexpr bool STAGE = DEMAP && !HARDONLY && (stage_wanted(CHUNK) || STG_BLOCKS > 1);
-#endif
     static constexpr int STG_STRIDE = stage_stride_bytes(CHUNK);
     static constexpr int STG_WAVE_BYTES = STAGE ? 64 * STG_STRIDE * STG_BLOCKS : 0;
     static constexpr int STG_BYTES = STG_WAVE_BYTES * (O::kWG / 64);
@@ -559,21 +462,13 @@ struct RxShape {
     // barrier for it, which costs more than it gains at N = 2048/4096 (measured) unless LDS is short:
     // the FULL variants there gain a workgroup per CU (4096/256-QAM + hard bits: 53 -> 59 %), and at
     // N = 8192 it is the difference between one and two workgroups per CU.
-#ifdef SDR_NO_STG_ALIAS
-    static constexpr bool STG_ALIAS = false;
-#else
-    static constexpr bool STG_ALIAS = STAGE && STG_BYTES <= SYM_BYTES * SPW && (O::kWG == 64 || LOG2N >= SDR_ALIAS_FROM || FULL || GROUP > 1);
-#endif
-    static_assert(GROUP == 1 || !STAGE || STG_ALIAS, "grouped symbols stage their LLRs inside their own exchange region");
+    static constexpr bool STG_ALIAS = STAGE && STG_BYTES <= SYM_BYTES * SPW && (O::kWG == 64 || LOG2N >= 13 || FULL);
     static constexpr int IDX_OFF = IDX_ALIAS ? (STG_ALIAS ? (STG_BYTES + 15) & ~15 : 0) : DATA_BYTES + TW_BYTES;
     static constexpr int REF_OFF = REF_ALIAS ? (IDX_OFF + IDX_RAW_BYTES + 15) & ~15 : DATA_BYTES + TW_BYTES + IDX_BYTES;
     static_assert(!IDX_ALIAS || IDX_OFF + IDX_RAW_BYTES <= DATA_BYTES, "aliased hard decisions fit the exchange region");
     static_assert(!REF_ALIAS || REF_OFF + REF_RAW_BYTES <= DATA_BYTES, "aliased reference bits fit the exchange region");
     static constexpr int STG_OFF = STG_ALIAS ? 0 : (DATA_BYTES + TW_BYTES + IDX_BYTES + REF_BYTES + 15) & ~15;
-    // shared taps (8 bytes) and weights (4 bytes) of one set, GROUP > 1 only
-    static constexpr int TAPS_OFF = (DATA_BYTES + TW_BYTES + IDX_BYTES + REF_BYTES + 15) & ~15;
-    static constexpr int TAPS_BYTES = GROUP > 1 ? 12 * N : 0;
-    static constexpr int LDS_USED = GROUP > 1 ? TAPS_OFF + TAPS_BYTES + 16 : (STG_ALIAS ? DATA_BYTES + TW_BYTES + IDX_BYTES + REF_BYTES : STG_OFF + STG_BYTES) + 16;
+    static constexpr int LDS_USED = (STG_ALIAS ? DATA_BYTES + TW_BYTES + IDX_BYTES + REF_BYTES : STG_OFF + STG_BYTES) + 16;
     // Resident workgroups per CU of the LLR-only kernels at N <= 1024.  These kernels are bound by the
     // memory system, and the memory system runs a 1 : bps/2 read/write mix FASTER with fewer symbols
     // in flight (a copy of this shape: 5.4 TB/s at 16 waves per CU, 6.0 at 4-5, tools/membench6/7),
@@ -584,9 +479,6 @@ struct RxShape {
     // with hard bits or counters measured best at what they already get).
     static constexpr int wg_per_cu_target()
     {
-#ifdef SDR_NO_WG_TARGET
-        return 0;
-#else
         if (FULL || EQ || HARDONLY || !DEMAP || BPS == 1) return 0;      // BPSK (2:1 read-dominated) was not part of the sweep
         switch (LOG2N) {
             case 6: return BPS <= 8 ? (BPS == 4 ? 9 : 8) : 0;
@@ -596,60 +488,47 @@ struct RxShape {
             case 10: return BPS == 4 ? 10 : BPS == 6 ? 9 : BPS == 8 ? 12 : 0;
             default: return 0;
         }
-#endif
     }
     static constexpr int LDS_THROTTLE = wg_per_cu_target() > 0 ? ((160 * 1024 / wg_per_cu_target()) & ~511) : 0;
     static constexpr int LDS_BYTES = LDS_USED > LDS_THROTTLE ? LDS_USED : LDS_THROTTLE;
 
     // How the LLR-only tap-holding variant gets its taps, per shape, from same-buffer A/Bs of two builds inside
     // one process (tools/abbench.py, profiles/r2_eq_straight_line_ab.txt):
-    //   0  run of two symbols, taps held in registers and requested ahead of the samples when the set changes
+    //   0  run of two symbols (seven where RUN says so), taps held in registers and requested ahead of the samples when the set changes
     //   1  straight-line, one symbol group per workgroup, taps requested unconditionally behind the samples
     //   2  straight-line, taps requested per symbol ahead of the first exchange barrier (LATE_TAPS)
-    //   3  straight-line, taps read in the epilogue SDR_EPI_AHEAD register groups ahead of their use (EPILOGUE_TAPS; N = 8192, 1024/1024-QAM)
-    //   4  straight-line, taps requested per symbol behind the last exchange read (LATE_TAPS with LATE_AT 2; N = 8192)
+    //   3  straight-line, taps read in the epilogue EPI_AHEAD register groups ahead of their use (EPILOGUE_TAPS; N = 8192, 1024/1024-QAM)
     static constexpr int eq_form()
     {
-#ifdef SDR_EQ_FORM_ALL      // experiment: one form everywhere
-        return SDR_EQ_FORM_ALL;
-#endif
-        if (BPS == 1) return LOG2N == 13 ? SDR_EQ_FORM_13 : SDR_EQ_FORM_BPSK;
+        if (BPS == 1) return LOG2N == 13 ? 3 : 0;
         switch (LOG2N) {
             case 6: return BPS == 2 ? 0 : 1;
             case 7: return BPS == 10 ? 0 : 1;
             case 8: return (BPS <= 4 || BPS == 10) ? 0 : 1;
             case 10: return BPS == 2 ? 0 : BPS == 10 ? 3 : 1;      // 1024-QAM: +3.2 with the epilogue form and its prefetch (the form loses 0.2 to 8.5 in every other cell below N = 8192)
             case 11: return (BPS == 2 || BPS == 10) ? 0 : BPS == 4 ? 1 : 2;
-            case 12: return BPS <= 4 ? 0 : BPS == 10 ? SDR_EQ_FORM_12_10 : 2;      // 1024-QAM: the run of two again since the unpacked build (-2.2 with the straight form)
-            case 13: return SDR_EQ_FORM_13;
+            case 12: return (BPS <= 4 || BPS == 10) ? 0 : 2;       // 1024-QAM: the run of two again since the unpacked build (-2.2 with the straight form)
+            case 13: return 3;
             default: return 0;      // N = 512: the run of two
         }
     }
-    // Alternative to holding the taps across a run of two symbols: requested per symbol ahead of an
-    // exchange barrier (SDR_LATE_AT: 0 = first exchange, 1 = second) -- 48 fewer live registers, three
-    // waves per SIMD instead of two, but twice the tap traffic through L2.  Round 1 measured it within a
-    // point of the run of two; against round 2's straight form it wins at N = 2048 (64-QAM up) and 4096
-    // (profiles/r2_eq_straight_line_ab.txt) and is what those shapes use.  Four waves per SIMD spill (-15 points).
-    static constexpr bool LATE_TAPS = EQ && DEMAP && O::kPasses == 3 && (FULL ? SDR_LATE_TAPS_FULL
-                                              : SDR_LATE_TAPS < 0 ? (eq_form() == 2 || eq_form() == 4 || (SDR_LATE_13 && LOG2N == 13))      // same-box A/B against the straight form: +0.6 to +1.4 points (2048/16-QAM: -0.7)
-                                                                  : (SDR_LATE_TAPS && LOG2N >= SDR_LATE_FROM && LOG2N <= 12));
+    // Form 2: requested per symbol ahead of the first exchange barrier -- 48 fewer live registers, three
+    // waves per SIMD instead of two, but twice the tap traffic through L2.  It wins at N = 2048 (64-QAM up) and 4096
+    // (profiles/r2_eq_straight_line_ab.txt).  Four waves per SIMD spill (-15 points).
+    static constexpr bool LATE_TAPS = EQ && DEMAP && O::kPasses == 3 && !FULL && eq_form() == 2;
+    static constexpr int LATE_AT = 0;
     // Only the tap-holding instantiations take a run of symbol groups per workgroup (taps reloaded
     // once per run).  The others take exactly one group and are straight-line code: nothing is
     // hoisted out of a loop into registers (N = 1024 LLR variant: 136 -> 104-119 registers; hard bits
     // beside LLRs: 63 -> 68 %; N = 8192: 56 -> 71 %).  Counting variants then end every symbol with
     // four atomics per wave on the 1024 counter slots, which measured no slower than runs of eight.
-    // (The name is historical: the run of two is written out, see `process` in the kernel.)
-    // Round 2: where it measured faster (same buffers, tools/occbench.py, profiles/r2_eq_straight_line_ab.txt)
-    // the tap-holding variant is straight-line too -- one symbol group per workgroup, taps and weights
+    // Form 1: the tap-holding variant is straight-line too -- one symbol group per workgroup, taps and weights
     // requested unconditionally BEHIND the samples, so that the wait in front of the transform covers the
     // samples only (vmcnt counts the tap loads as still outstanding) and the taps land during it.  Twice
     // the tap requests through L2, but three waves per SIMD instead of two and no loads queued behind a
     // previous symbol's stores: +1 to +7 points at N = 64...256, 1024 (16-QAM up), 2048, 4096; N = 512 and
     // QPSK at 1024 lose 0.4 to 6.7 points with it and N = 8192 is level: those keep the run of two.
-#ifdef SDR_EQ_TAPS_AFTER
-    static constexpr bool EQ_STRAIGHT_RULE = true;
-#else
-    // every-output variants (hard bits, counters beside LLRs; same tool, N:bps:eq:hard): straight wins +1.5 to +7.1 at
+    // Every-output variants (hard bits, counters beside LLRs; same tool, N:bps:eq:hard): straight wins +1.5 to +7.1 at
     // 64 / 256 from 64-QAM, 256 everywhere, 1024 at 256-QAM, 2048 from 16-QAM to 256-QAM; loses 1.4 to 5.4 at 512, 4096, QPSK
     static constexpr bool full_straight()
     {
@@ -662,42 +541,39 @@ struct RxShape {
         }
     }
     static constexpr bool EQ_STRAIGHT_RULE = FULL ? full_straight() : (eq_form() == 1);
-#endif
-    static constexpr int LATE_AT = (eq_form() == 4) ? SDR_LATE_AT_13 : SDR_LATE_AT;
-    // N = 8192 (E = 32): 96 tap registers beside 64 of data and the last pass's twiddles do not fit 256
+    // Form 3.  N = 8192 (E = 32): 96 tap registers beside 64 of data and the last pass's twiddles do not fit 256
     // (one wave per SIMD, or spills with late taps); there the epilogue reads each register group's taps
-    // and weights right where it uses them and leaves the hoisting to the compiler.
-#ifndef SDR_EPILOGUE_TAPS_13
-#define SDR_EPILOGUE_TAPS_13 1      // same-box A/B: +0.2 to +9.5 points over one wave per SIMD with held taps (profiles/r2_eq_straight_line_ab.txt)
-#endif
-    // The every-output variants with taps take the same form from SDR_EPILOGUE_TAPS_FULL_FROM on, at N = 1024 and at 1024-QAM:
+    // and weights EPI_AHEAD groups ahead of where it uses them (+0.2 to +9.5 points over one wave per SIMD with held taps).
+    // The every-output variants with taps take the same form from N = 4096 on, at N = 1024 and at 1024-QAM:
     // held taps cost them 50 to 100 spilled registers at N = 8192 with two waves per SIMD (+3.4 to +14.8 points,
     // same-buffer A/B); N = 4096: +2.5 to +6.7; 1024-QAM: -0.1 to +5.2; N = 1024: +0.6 to +4.9; the other shapes: -1.7 to +1.1, left alone.
-#ifndef SDR_EPILOGUE_TAPS_FULL_FROM
-#define SDR_EPILOGUE_TAPS_FULL_FROM 12
-#endif
-    static constexpr bool EPILOGUE_TAPS = EQ && DEMAP && GROUP == 1 && SDR_EPILOGUE_TAPS_13 && (FULL ? (LOG2N >= SDR_EPILOGUE_TAPS_FULL_FROM || BPS == 10 || LOG2N == 10) : eq_form() == 3);
+    static constexpr bool EPILOGUE_TAPS = EQ && DEMAP && (FULL ? (LOG2N >= 12 || BPS == 10 || LOG2N == 10) : eq_form() == 3);
+    // taps of register group h + EPI_AHEAD requested before group h is worked on: same-buffer A/B at N = 8192: BPSK 32.4 -> 49.3 %,
+    // QPSK 42.7 -> 56.6, 16-QAM 50.3 -> 60.0, the others +0.2 to +1.0 (8: level, 1024-QAM -1.6)
+    static constexpr int EPI_AHEAD = 4;
     // Non-temporal sample loads in the tap-reading variants: the samples are read once, the taps of a set
     // by up to 14 workgroups.  Same-buffer A/B (tools/abbench.py): +0.4 to +2.5 points at N = 1024, +0.9 to
     // +11.3 at N = 8192 (64-QAM: 47.7 -> 59.0 %), level (-0.5 ... +0.2) at the other sizes, which keep plain
     // loads; the variants without taps lose up to 1.7 points with them.
-#ifdef SDR_NT_LOADS
-    static constexpr bool NT_SAMPLES = true;
-#else
-    static constexpr bool NT_SAMPLES = EQ && DEMAP && (SDR_NT_EQ == 1 || (SDR_NT_EQ < 0 && (LOG2N == 10 || LOG2N == 13)));
-#endif
-    static constexpr bool EQ_STRAIGHT = EQ && DEMAP && !LATE_TAPS && GROUP == 1 && EQ_STRAIGHT_RULE && !SDR_EQ_FORCE_LOOP;
+    static constexpr bool NT_SAMPLES = EQ && DEMAP && (LOG2N == 10 || LOG2N == 13);
+    static constexpr bool EQ_STRAIGHT = EQ && DEMAP && !LATE_TAPS && EQ_STRAIGHT_RULE;
     static constexpr bool TAPS_AFTER = EQ_STRAIGHT;
     // Symbol groups per workgroup of the loop form (taps reloaded when the set changes, i.e. once per run inside a set).
     // Seven, as a real loop, where the taps' way through L2 weighs most against the symbol's own bytes (same-buffer
     // A/B against the run of two: N = 4096 BPSK +4.9, QPSK +4.2, 1024-QAM +1.3; N = 2048 +2.3 / +1.6 / +0.8);
     // it loses 0.4 to 4.5 points at N <= 1024 and at 4096/16-QAM, and fourteen is no better than seven.
-#ifdef SDR_EQ_RUN
-    static constexpr int RUN = SDR_EQ_RUN;
-#else
     static constexpr int RUN = ((LOG2N == 11 || LOG2N == 12) && (BPS <= 2 || BPS == 10)) ? 7 : 2;
-#endif
-    static constexpr bool LOOP = EQ && !LATE_TAPS && !SDR_EQ_NOLOOP && GROUP == 1 && !EQ_STRAIGHT && !EPILOGUE_TAPS;
+    static constexpr bool LOOP = EQ && !LATE_TAPS && !EQ_STRAIGHT && !EPILOGUE_TAPS;
+    // The middle pass's twiddle table is written to LDS BEHIND the request for the first symbol's samples: the
+    // workgroup then waits for one memory round trip instead of two in a row (table, then samples).  The kernels
+    // bound by HBM lose 1.8 to 6.1 points with it at N = 1024 ... 4096 (same-buffer A/B, round 2) and keep the set-up's
+    // own wait; the hard-only kernel, whose waves spent 35 % of their life in s_waitcnt with two such round
+    // trips per symbol (profiles/r3_pmc_hard_only_65536sym.txt), takes it: +0.9 to +1.2 points at N = 512 ... 8192
+    // (profiles/r3_hard_only_table_late_and_prefetch_ab.txt; the counting variants +0.2 to +0.5, left alone).
+    static constexpr bool TW_LATE = HARDONLY;
+    // The XCD-aware workgroup order makes each XCD's STORES one sequential stream.  The hard-only kernel reads ten
+    // times what it writes and runs 0.5 to 1.5 points faster in the natural order (same file).
+    static constexpr bool XCD_ORDER = !HARDONLY;
 
     // Waves per SIMD.  Lower bound = register budget: the tap-holding and FULL variants must not
     // drift to 256+ registers (one wave per SIMD); at N = 8192 (E = 32) FULL variants are held to
@@ -708,20 +584,11 @@ struct RxShape {
     // 168 registers, i.e. three waves per SIMD: 73 %).  The compiler pads the allocation for it.
     static constexpr int WAVES_PER_WG = WG_THREADS / 64;
     static constexpr int LDS_WAVES = (160 * 1024 / ((LDS_BYTES + 511) & ~511)) * WAVES_PER_WG;
-#ifdef SDR_WPE
-    static constexpr int MIN_WAVES = SDR_WPE, MAX_WAVES = SDR_WPE;
-#else
-#ifndef SDR_HARD_WPE
-#define SDR_HARD_WPE 1
-#endif
-    static constexpr int MIN_WAVES = GROUP > 1 ? 1 : (HARDONLY && LOG2N <= 10) ? SDR_HARD_WPE : LOG2N >= 13 ? (LATE_TAPS ? SDR_LATE_13_WPE : EPILOGUE_TAPS ? 2 : (FULL && IDX_ALIAS) ? 2 : (FULL || EQ || HARDONLY) ? 1 : 2) : FULL ? SDR_EQ_WPE : EQ ? (LATE_TAPS ? SDR_LATE_WPE : SDR_EQ_WPE) : 1;
+    static constexpr int MIN_WAVES = (HARDONLY && LOG2N <= 10) ? 1
+                                     : LOG2N >= 13 ? (EPILOGUE_TAPS ? 2 : (FULL && IDX_ALIAS) ? 2 : (FULL || EQ || HARDONLY) ? 1 : 2)
+                                     : FULL ? 2 : EQ ? (LATE_TAPS ? 3 : 2) : 1;
     static constexpr int even_share() { const int w = (LDS_WAVES + 3) / 4; return w < 1 ? 1 : w > 8 ? 8 : w; }
-#ifdef SDR_NO_MAX_WAVES
-    static constexpr int MAX_WAVES = 8;
-#else
     static constexpr int MAX_WAVES = even_share() < MIN_WAVES ? MIN_WAVES : even_share();
-#endif
-#endif
 };
 
 // MI + MQ == 0: FFT only (bins to p.fft).  FULL: every output optional at run time.
@@ -729,14 +596,14 @@ struct RxShape {
 // set, or requested per symbol: RxShape::LATE_TAPS; costs registers, hence a separate instantiation).
 // HARDONLY: packed hard decisions are the only output (the reference's own chain ofdm::rx ->
 // from_constl, lib/inc/ofdm.hpp:37-43 + modulation.hpp:96-112): no LLR arithmetic at all.
-template <int LOG2N, int MI, int MQ, bool FULL, bool EQ, bool HARDONLY = false, int GROUP = 1>
-__global__ void __launch_bounds__(PlanOps<LOG2N>::kWG * GROUP)
-    __attribute__((amdgpu_waves_per_eu(RxShape<LOG2N, MI, MQ, FULL, EQ, HARDONLY, GROUP>::MIN_WAVES, RxShape<LOG2N, MI, MQ, FULL, EQ, HARDONLY, GROUP>::MAX_WAVES)))
+template <int LOG2N, int MI, int MQ, bool FULL, bool EQ, bool HARDONLY = false, bool NOWGT = false>
+__global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
+    __attribute__((amdgpu_waves_per_eu(RxShape<LOG2N, MI, MQ, FULL, EQ, HARDONLY, NOWGT>::MIN_WAVES, RxShape<LOG2N, MI, MQ, FULL, EQ, HARDONLY, NOWGT>::MAX_WAVES)))
     rx_fused_kernel(const RxParams p)
 {
     using O = PlanOps<LOG2N>;
     using P = typename O::P;
-    using S = RxShape<LOG2N, MI, MQ, FULL, EQ, HARDONLY, GROUP>;
+    using S = RxShape<LOG2N, MI, MQ, FULL, EQ, HARDONLY, NOWGT>;
     using idx_t = typename S::idx_t;
     constexpr int N = O::kN, E = O::kE, TPS = O::kTPS, SPW = O::kSPW, LAST = O::kLast;
     constexpr int BPS = S::BPS;
@@ -750,23 +617,20 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG * GROUP)
     [[maybe_unused]] idx_t* lds_idx = reinterpret_cast<idx_t*>(lds + S::IDX_OFF);
     [[maybe_unused]] unsigned char* lds_ref = lds + S::REF_OFF;
 
-    // GROUP > 1: `tid` is the thread's id inside its symbol's kWG threads, `gslot` the symbol's place in the workgroup
-    const int gslot = GROUP > 1 ? static_cast<int>(threadIdx.x) / O::kWG : 0;
-    const int tid = GROUP > 1 ? static_cast<int>(threadIdx.x) % O::kWG : static_cast<int>(threadIdx.x);
-    const int slot = GROUP > 1 ? gslot : SPW == 1 ? 0 : tid / TPS;        // exchange region of the thread's symbol
+    const int tid = static_cast<int>(threadIdx.x);
+    const int slot = SPW == 1 ? 0 : tid / TPS;                            // exchange region of the thread's symbol
     const int t = SPW == 1 ? tid : tid % TPS;
-    constexpr int SPG = SPW * GROUP;                                      // symbols per workgroup
-    constexpr bool WAVE_SYNC = GROUP > 1 && O::kWG == 64;
+    constexpr int SPG = SPW;                                              // symbols per symbol group
 
     // ---- per-workgroup set-up: addresses and twiddles ----
     FftAddr<LOG2N> addr;
     addr.init(t, slot, SYM_BYTES);
     FftTwiddles<LOG2N> tw;
     // the middle pass's table: all of a thread's entries requested together, then written to LDS (one wait instead of a
-    // load-wait-store loop: level, -0.6 ... +0.9; writing it behind the request for the samples, SDR_TW_PARK_LATE, loses)
+    // load-wait-store loop: level, -0.6 ... +0.9); S::TW_LATE: written behind the request for the first symbol's samples
     tw.request(p.tw, reinterpret_cast<float2*>(lds + DATA_BYTES), tid, addr);
-    [[maybe_unused]] bool tw_parked = !SDR_TW_PARK_LATE;
-    if constexpr (!SDR_TW_PARK_LATE) tw.park(tid);
+    [[maybe_unused]] bool tw_parked = !S::TW_LATE;
+    if constexpr (!S::TW_LATE) tw.park(tid);
     const int pos_last = addr.pos_last;
     const int in_thread = addr.in_thread;
 
@@ -774,7 +638,7 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG * GROUP)
 
     const unsigned long long n_groups = (p.n_sym + SPG - 1) / SPG;
     const size_t in_stride = static_cast<size_t>(N) + p.cp;
-    if constexpr (O::kMidCount > 0 && !SDR_TW_PARK_LATE) __syncthreads();
+    if constexpr (O::kMidCount > 0 && !S::TW_LATE) __syncthreads();
 
     // global load of one symbol into registers: CP skipped, bit reversal folded into the index
     auto load_symbol = [&](unsigned long long grp_, float2 (&dst)[E]) {
@@ -810,7 +674,7 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG * GROUP)
     // whole grid (one contiguous eighth of the batch per XCD: +1 to +3 points over windows of 4096
     // on 1 Mi-symbol batches, tools/sweep_xcd_window.sh).  Speed only, never correctness.
     unsigned long long wg = blockIdx.x;
-    if (p.xcd_window >= 8) {
+    if (S::XCD_ORDER && p.xcd_window >= 8) {
         const unsigned long long win = p.xcd_window;
         const unsigned long long full = (static_cast<unsigned long long>(gridDim.x) / win) * win;
         if (wg < full) {
@@ -821,9 +685,9 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG * GROUP)
     const unsigned long long grp_begin = wg * p.groups_per_wg;
     const unsigned long long grp_end = (grp_begin + p.groups_per_wg < n_groups) ? grp_begin + p.groups_per_wg : n_groups;
     float2 x[E];
-    constexpr bool PREFETCH_TAPS = EQ && DEMAP && GROUP == 1 && !S::EPILOGUE_TAPS;
+    constexpr bool PREFETCH_TAPS = EQ && DEMAP && !S::EPILOGUE_TAPS;
     [[maybe_unused]] float2 eqv[PREFETCH_TAPS ? E : 1];
-    [[maybe_unused]] float wv[PREFETCH_TAPS ? E : 1];
+    [[maybe_unused]] float wv[(PREFETCH_TAPS && !NOWGT) ? E : 1];
     [[maybe_unused]] size_t held_set = ~static_cast<size_t>(0);     // set whose taps the registers hold
     if (grp_begin >= grp_end) return;      // uniform over the workgroup
     // One symbol group, as a body that the tap-holding variants run twice: written out, because a
@@ -849,35 +713,22 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG * GROUP)
             if constexpr (PREFETCH_TAPS) {
             constexpr int GO_ = O::kGroupOut;
             const float2* dummy = p.rx + static_cast<size_t>(sym) * in_stride;      // >= N readable float2
-#ifdef SDR_EQ_SET0      // experiment: every symbol reads the taps of set 0 (cache-resident)
-            const float2* eq_src = p.eq ? p.eq : dummy;
-            const float* wgt_src = p.wgt ? p.wgt : reinterpret_cast<const float*>(dummy);
-#else
             const float2* eq_src = p.eq ? p.eq + tap_set * N : dummy;
-            const float* wgt_src = p.wgt ? p.wgt + tap_set * N : reinterpret_cast<const float*>(dummy);
-#endif
-#ifdef SDR_EQ_NOLOAD    // experiment: no tap traffic at all, run-time values the compiler cannot fold
-            static_for<E>([&](auto M) { constexpr int m = M; eqv[m] = make_float2(p.w0, p.inorm); wv[m] = p.w0; });
-            (void)eq_src; (void)wgt_src;
-            if (true) return;
-#endif
+            [[maybe_unused]] const float* wgt_src = p.wgt ? p.wgt + tap_set * N : reinterpret_cast<const float*>(dummy);
             static_for<E / GO_>([&](auto Hh) {
                 constexpr int h = Hh;
                 const int k = O::reg_pos(LAST, h * GO_) | pos_last;
                 if constexpr (GO_ == 2) {
-#ifdef SDR_EQ_NT_TAPS
-                    const sdr_v4f v = __builtin_nontemporal_load(reinterpret_cast<const sdr_v4f*>(eq_src + k));
-                    const sdr_v2f u = __builtin_nontemporal_load(reinterpret_cast<const sdr_v2f*>(wgt_src + k));
-#else
                     const float4 v = *reinterpret_cast<const float4*>(eq_src + k);
-                    const float2 u = *reinterpret_cast<const float2*>(wgt_src + k);
-#endif
                     eqv[h * 2] = make_float2(v.x, v.y);
                     eqv[h * 2 + 1] = make_float2(v.z, v.w);
-                    wv[h * 2] = u.x;
-                    wv[h * 2 + 1] = u.y;
+                    if constexpr (!NOWGT) {
+                        const float2 u = *reinterpret_cast<const float2*>(wgt_src + k);
+                        wv[h * 2] = u.x;
+                        wv[h * 2 + 1] = u.y;
+                    }
                 } else {
-                    static_for<GO_>([&](auto G) { constexpr int g = G; eqv[h * GO_ + g] = eq_src[k + g]; wv[h * GO_ + g] = wgt_src[k + g]; });
+                    static_for<GO_>([&](auto G) { constexpr int g = G; eqv[h * GO_ + g] = eq_src[k + g]; if constexpr (!NOWGT) wv[h * GO_ + g] = wgt_src[k + g]; });
                 }
             });
             }
@@ -906,44 +757,9 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG * GROUP)
             });
         }
 
-        // GROUP > 1: the workgroup's threads fetch the set's taps and weights once, two or three
-        // 16-byte loads per thread requested ahead of the samples, and park them in LDS for the epilogues
-        // of all GROUP symbols (index clamped: surplus threads repeat the last vector).
-        constexpr int WGT = S::WG_THREADS;
-        constexpr int NE = (N / 2 + WGT - 1) / WGT;        // float4 = two taps
-        constexpr int NW = (N / 4 + WGT - 1) / WGT;        // float4 = four weights
-        [[maybe_unused]] float4 tap_e[GROUP > 1 ? NE : 1];
-        [[maybe_unused]] float4 tap_w[GROUP > 1 ? NW : 1];
-        if constexpr (GROUP > 1) {
-            static_assert(O::kGroupOut == 2, "grouped symbols read their taps as pairs of adjacent bins");
-            const size_t gset = p.sym_per_set ? static_cast<size_t>((grp * SPG) / p.sym_per_set) : 0;
-            const float2* dummy = p.rx + static_cast<size_t>(sym) * in_stride;      // >= N readable float2, 16-byte aligned
-            const float4* e4 = reinterpret_cast<const float4*>(p.eq ? p.eq + gset * N : dummy);
-            const float4* w4 = reinterpret_cast<const float4*>(p.wgt ? p.wgt + gset * N : reinterpret_cast<const float*>(dummy));
-            const int wtid = static_cast<int>(threadIdx.x);
-#ifdef SDR_EQ_NOLOAD    // experiment: the grouped structure without any tap traffic
-            static_for<NE>([&](auto J) { constexpr int j = J; tap_e[j] = make_float4(p.w0, p.inorm, p.w0, p.inorm); });
-            static_for<NW>([&](auto J) { constexpr int j = J; tap_w[j] = make_float4(p.w0, p.w0, p.w0, p.w0); });
-            (void)e4; (void)w4; (void)wtid;
-#else
-            static_for<NE>([&](auto J) { constexpr int j = J; int i = j * WGT + wtid; if (i > N / 2 - 1) i = N / 2 - 1; tap_e[j] = e4[i]; });
-            static_for<NW>([&](auto J) { constexpr int j = J; int i = j * WGT + wtid; if (i > N / 4 - 1) i = N / 4 - 1; tap_w[j] = w4[i]; });
-#endif
-        }
-
         // ---- pass 0 ----
         load_symbol(grp, x);
-        if constexpr (SDR_TW_PARK_LATE) if (!tw_parked) { tw.park(tid); tw_parked = true; }
-        if constexpr (GROUP > 1) {
-            float4* lds_e = reinterpret_cast<float4*>(lds + S::TAPS_OFF);
-            float4* lds_w = reinterpret_cast<float4*>(lds + S::TAPS_OFF + 8 * N);
-            const int wtid = static_cast<int>(threadIdx.x);
-            static_for<NE>([&](auto J) { constexpr int j = J; int i = j * WGT + wtid; if (i > N / 2 - 1) i = N / 2 - 1; lds_e[i] = tap_e[j]; });
-            static_for<NW>([&](auto J) { constexpr int j = J; int i = j * WGT + wtid; if (i > N / 4 - 1) i = N / 4 - 1; lds_w[i] = tap_w[j]; });
-            // The workgroup's only barrier sits HERE, while the samples are still on their way: from now
-            // on the GROUP symbols run independently (one-wave symbols: no further barrier at all).
-            __syncthreads();
-        }
+        if constexpr (S::TW_LATE) if (!tw_parked) { tw.park(tid); tw_parked = true; }      // the exchange barriers of pass 0 lie between this and the table's first use
         if constexpr (PREFETCH_TAPS && !LATE_TAPS && S::TAPS_AFTER) load_taps();      // straight-line: unconditional, behind the samples
         auto park_ref = [&]() {
             static_for<REF_PER_THREAD>([&](auto R) {
@@ -959,14 +775,13 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG * GROUP)
             auto late = [&]() { load_taps(); };
             fft_run<LOG2N, false, decltype(late), S::LATE_AT>(x, lds_data, addr, tw, std::move(late));
         } else {
-            fft_run<LOG2N, false, NoLateWork, 1, WAVE_SYNC>(x, lds_data, addr, tw);
+            fft_run<LOG2N>(x, lds_data, addr, tw);
         }
-
-        // every wave is past its last exchange read (staging strips alias it); GROUP > 1: the shared taps are in LDS
+        // every wave is past its last exchange read (staging strips alias it)
         if constexpr ((STG_ALIAS || S::IDX_ALIAS) && O::kWG > 64) __syncthreads();
         if constexpr (S::REF_ALIAS) {      // reference bits into the dead exchange region, visible to the symbol's other threads
             park_ref();
-            if constexpr (O::kWG > 64) __syncthreads(); else symbol_sync<true>();
+            if constexpr (O::kWG > 64) __syncthreads(); else wave_lds_sync();
         }
 
         // ---- epilogue: bins are in natural order, k = reg_pos(LAST, m) | pos_last ----
@@ -975,7 +790,7 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG * GROUP)
         // Bins out with several symbols per wave whose per-block run (TPS * GO bins) is half a cache line (N = 64): two
         // consecutive blocks go through the dead exchange region (one-wave workgroups: LDS ops are in order) so that
         // every store covers whole 128-byte lines.
-        constexpr bool BINS_STAGED = SDR_BINS_STAGED && SPW > 1 && O::kWG == 64 && GROUP == 1 && (TPS * GO * 8) % 128 != 0 && (2 * TPS * GO * 8) % 128 == 0
+        constexpr bool BINS_STAGED = SPW > 1 && O::kWG == 64 && (TPS * GO * 8) % 128 != 0 && (2 * TPS * GO * 8) % 128 == 0
                                      && (E / GO) % 2 == 0 && 64 * GO * 2 * 2 * 4 <= DATA_BYTES;
         if constexpr ((!DEMAP || FULL) && BINS_STAGED) {
             if (p.fft) {
@@ -988,7 +803,7 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG * GROUP)
                     float* mine = stg + (((lane / TPS) * NBB + hb) * TPS + (lane % TPS)) * CB;
                     static_for<GO>([&](auto G) { constexpr int g = G; *reinterpret_cast<float2*>(mine + 2 * g) = x[h * GO + g]; });
                     if constexpr (hb == NBB - 1) {
-                        symbol_sync<true>();      // one wave: LDS serves its instructions in order, the fences keep the compiler from reordering them
+                        wave_lds_sync();      // one wave: LDS serves its instructions in order, the fences keep the compiler from reordering them
                         constexpr int RUN = TPS * CB * NBB;                  // floats per symbol in the group
                         constexpr int NV = 64 * CB * NBB / 4;
                         static_assert(RUN % 4 == 0 && NV % 64 == 0, "whole vectors, whole wave");
@@ -1002,7 +817,7 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG * GROUP)
                                 *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.fft + static_cast<size_t>(dsym) * N + O::reg_pos(LAST, h0 * GO)) + off) = q4;
                             }
                         });
-                        symbol_sync<true>();      // one wave: LDS serves its instructions in order, the fences keep the compiler from reordering them
+                        wave_lds_sync();      // one wave: LDS serves its instructions in order, the fences keep the compiler from reordering them
                     }
                 });
             }
@@ -1020,25 +835,27 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG * GROUP)
             }
         }
         if constexpr (DEMAP) {
-            // EPILOGUE_TAPS with SDR_EPI_AHEAD > 0: the taps of register group h + AHEAD are requested before group h
+            // EPILOGUE_TAPS: the taps of register group h + AHEAD are requested before group h
             // is worked on (the run-time branches on p.eq / p.wgt and the staging barriers end the compiler's scheduling
             // regions, so it hoists nothing across groups by itself: one exposed memory latency per group).
             constexpr int NBLK = E / GO;
-            constexpr int AHEAD = S::EPILOGUE_TAPS ? (SDR_EPI_AHEAD < NBLK ? SDR_EPI_AHEAD : NBLK) : 0;
+            constexpr int AHEAD = S::EPILOGUE_TAPS ? (S::EPI_AHEAD < NBLK ? S::EPI_AHEAD : NBLK) : 0;
             [[maybe_unused]] float2 epv[AHEAD > 0 ? E : 1];
-            [[maybe_unused]] float epw[AHEAD > 0 ? E : 1];
+            [[maybe_unused]] float epw[(AHEAD > 0 && !NOWGT) ? E : 1];
             [[maybe_unused]] auto epi_load = [&]<int H_>() {
                 const float2* dummy = p.rx + static_cast<size_t>(sym) * in_stride;
                 const float2* eq_src = p.eq ? p.eq + tap_set * N : dummy;
-                const float* wgt_src = p.wgt ? p.wgt + tap_set * N : reinterpret_cast<const float*>(dummy);
+                [[maybe_unused]] const float* wgt_src = p.wgt ? p.wgt + tap_set * N : reinterpret_cast<const float*>(dummy);
                 const int k = O::reg_pos(LAST, H_ * GO) | pos_last;
                 if constexpr (GO == 2) {
                     const float4 v = *reinterpret_cast<const float4*>(eq_src + k);
-                    const float2 u = *reinterpret_cast<const float2*>(wgt_src + k);
                     epv[H_ * 2] = make_float2(v.x, v.y); epv[H_ * 2 + 1] = make_float2(v.z, v.w);
-                    epw[H_ * 2] = u.x; epw[H_ * 2 + 1] = u.y;
+                    if constexpr (!NOWGT) {
+                        const float2 u = *reinterpret_cast<const float2*>(wgt_src + k);
+                        epw[H_ * 2] = u.x; epw[H_ * 2 + 1] = u.y;
+                    }
                 } else {
-                    static_for<GO>([&](auto G) { constexpr int g = G; epv[H_ * GO + g] = eq_src[k + g]; epw[H_ * GO + g] = wgt_src[k + g]; });
+                    static_for<GO>([&](auto G) { constexpr int g = G; epv[H_ * GO + g] = eq_src[k + g]; if constexpr (!NOWGT) epw[H_ * GO + g] = wgt_src[k + g]; });
                 }
             };
             if constexpr (AHEAD > 0) static_for<AHEAD>([&](auto Hh) { constexpr int h = Hh; epi_load.template operator()<h>(); });
@@ -1052,20 +869,8 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG * GROUP)
                 // array is missing) so that the compiler can count and hoist the loads
                 [[maybe_unused]] float2 epi_eq[GO];
                 [[maybe_unused]] float epi_w[GO];
-                if constexpr (S::EPILOGUE_TAPS && AHEAD > 0) {
-                    static_for<GO>([&](auto G) { constexpr int g = G; epi_eq[g] = epv[h * GO + g]; epi_w[g] = epw[h * GO + g]; });
-                } else if constexpr (S::EPILOGUE_TAPS) {
-                    const float2* dummy = p.rx + static_cast<size_t>(sym) * in_stride;
-                    const float2* eq_src = p.eq ? p.eq + tap_set * N : dummy;
-                    const float* wgt_src = p.wgt ? p.wgt + tap_set * N : reinterpret_cast<const float*>(dummy);
-                    if constexpr (GO == 2) {
-                        const float4 v = *reinterpret_cast<const float4*>(eq_src + k);
-                        const float2 u = *reinterpret_cast<const float2*>(wgt_src + k);
-                        epi_eq[0] = make_float2(v.x, v.y); epi_eq[1] = make_float2(v.z, v.w);
-                        epi_w[0] = u.x; epi_w[1] = u.y;
-                    } else {
-                        static_for<GO>([&](auto G) { constexpr int g = G; epi_eq[g] = eq_src[k + g]; epi_w[g] = wgt_src[k + g]; });
-                    }
+                if constexpr (S::EPILOGUE_TAPS) {
+                    static_for<GO>([&](auto G) { constexpr int g = G; epi_eq[g] = epv[h * GO + g]; if constexpr (!NOWGT) epi_w[g] = epw[h * GO + g]; });
                 }
                 static_for<GO>([&](auto G) {
                     constexpr int g = G;
@@ -1075,18 +880,19 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG * GROUP)
                         if (p.eq) {
                             float2 gk;
                             if constexpr (PREFETCH_TAPS) gk = eqv[h * GO + g];
-                            else if constexpr (GROUP > 1) gk = reinterpret_cast<const float2*>(lds + S::TAPS_OFF)[k + g];
-                            else if constexpr (S::EPILOGUE_TAPS) gk = epi_eq[g];
-                            else gk = p.eq[tap_set * N + k + g];
+                            else gk = epi_eq[g];
                             const float er = y.x * gk.x - y.y * gk.y;
                             const float ei = y.x * gk.y + y.y * gk.x;
                             y.x = er; y.y = ei;
+                            // no weight array: w_k = w0 / |G_k|^2 (= norm^2 |H_k|^2 / N0 for zero-forcing taps), one correctly
+                            // rounded division per bin (uniform branch)
+                            if (p.w_from_taps) w = p.w0 / (gk.x * gk.x + gk.y * gk.y);
                         }
-                        if (p.wgt) {
-                            if constexpr (PREFETCH_TAPS) w = wv[h * GO + g];
-                            else if constexpr (GROUP > 1) w = reinterpret_cast<const float*>(lds + S::TAPS_OFF + 8 * N)[k + g];
-                            else if constexpr (S::EPILOGUE_TAPS) w = epi_w[g];
-                            else w = p.wgt[tap_set * N + k + g];
+                        if constexpr (!NOWGT) {
+                            if (p.wgt) {
+                                if constexpr (PREFETCH_TAPS) w = wv[h * GO + g];
+                                else w = epi_w[g];
+                            }
                         }
                     }
                     idx[g] = demap_point<float, MI, MQ, !HARDONLY, HARD_PATH>(y.x, y.y, p.inorm, w, l + g * BPS);
@@ -1097,14 +903,14 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG * GROUP)
                     // copy is wave-wide and checks the destination symbol, not the lane's own.
                     if (p.llr && (SPW > 1 || active)) {
                         // a strip without padding is linear memory: 16-byte vectors may straddle lanes
-                        constexpr bool LINEAR = SDR_LINEAR_STRIP && STG_STRIDE == CHUNK * 4 && (64 * CHUNK) % 4 == 0;
+                        constexpr bool LINEAR = STG_STRIDE == CHUNK * 4 && (64 * CHUNK) % 4 == 0;
                         constexpr int VW = (CHUNK % 4 == 0 || LINEAR) ? 4 : 2;   // floats per vector
                         constexpr int NB = S::STG_BLOCKS;                        // blocks staged together (N = 64: two)
                         constexpr int hb = h % NB, h0 = h - hb;
                         constexpr int NV = 64 * CHUNK * NB / VW;                 // vectors per wave and staged group
                         constexpr int VPL = CHUNK / VW;                          // vectors per lane (padded strips)
                         const int lane = tid & 63;
-                        float* stg = reinterpret_cast<float*>(lds + STG_OFF + (GROUP > 1 ? gslot * SYM_BYTES : 0) + (tid >> 6) * STG_WAVE_BYTES);
+                        float* stg = reinterpret_cast<float*>(lds + STG_OFF + (tid >> 6) * STG_WAVE_BYTES);
                         if constexpr (NB == 1) {
                             store_floats<CHUNK>(stg + lane * (STG_STRIDE / 4), l);
                         } else {
@@ -1114,7 +920,7 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG * GROUP)
                             store_floats<CHUNK>(stg + (((lane / TPS) * NB + hb) * TPS + (lane % TPS)) * CHUNK, l);
                         }
                         if constexpr (hb == NB - 1) {
-                        symbol_sync<true>();      // one wave: LDS serves its instructions in order, the fences keep the compiler from reordering them
+                        wave_lds_sync();      // one wave: LDS serves its instructions in order, the fences keep the compiler from reordering them
                         constexpr int gbits = O::kLogE - P::kR[LAST];
                         float* gbase = p.llr + (bin0 + O::reg_pos(LAST, h0 * GO) + ((tid & ~63) << gbits)) * BPS;
                         static_for<(NV + 63) / 64>([&](auto I) {
@@ -1145,7 +951,7 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG * GROUP)
                                 }
                             }
                         });
-                        symbol_sync<true>();      // one wave: LDS serves its instructions in order, the fences keep the compiler from reordering them
+                        wave_lds_sync();      // one wave: LDS serves its instructions in order, the fences keep the compiler from reordering them
                         }      // last block of the staged group
                     }
                 } else if constexpr (!HARDONLY) {
@@ -1265,14 +1071,14 @@ struct RxTuning {
 RxTuning& rx_tuning_mutable();      // rx_fused.hip
 inline const RxTuning& rx_tuning() { return rx_tuning_mutable(); }
 
-template <int LOG2N, int MI, int MQ, bool FULL, bool EQ, bool HARDONLY = false, int GROUP = 1>
+template <int LOG2N, int MI, int MQ, bool FULL, bool EQ, bool HARDONLY = false, bool NOWGT = false>
 int launch_rx_fused(sdr_ctx* ctx, const RxParams& p)
 {
     using O = PlanOps<LOG2N>;
-    using S = RxShape<LOG2N, MI, MQ, FULL, EQ, HARDONLY, GROUP>;
-    auto kern = rx_fused_kernel<LOG2N, MI, MQ, FULL, EQ, HARDONLY, GROUP>;
+    using S = RxShape<LOG2N, MI, MQ, FULL, EQ, HARDONLY, NOWGT>;
+    auto kern = rx_fused_kernel<LOG2N, MI, MQ, FULL, EQ, HARDONLY, NOWGT>;
     const RxTuning& tune = rx_tuning();
-    const unsigned long long n_groups = (p.n_sym + O::kSPW * GROUP - 1) / (O::kSPW * GROUP);
+    const unsigned long long n_groups = (p.n_sym + O::kSPW - 1) / O::kSPW;
     // One symbol group per workgroup (with the XCD-aware order: +1.5 to +5 points over runs of two
     // at N = 512 ... 4096, and far better than a resident grid striding over the batch; the
     // per-workgroup twiddle set-up is cheap, the finer grain balances better).  The tap-holding
@@ -1282,7 +1088,7 @@ int launch_rx_fused(sdr_ctx* ctx, const RxParams& p)
         int nb = 0;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, S::WG_THREADS, static_cast<size_t>(tune.lds_pad > 0 ? tune.lds_pad : 0));
         if (e != hipSuccess) return fail_hip(e, "hipOccupancyMaxActiveBlocksPerMultiprocessor");
-        fprintf(stderr, "[sdr] rx_fused<%d,%d,%d,%d,%d,%d,%d>: %d threads/WG, %d WG/CU, %d CUs\n", LOG2N, MI, MQ, int(FULL), int(EQ), int(HARDONLY), GROUP, S::WG_THREADS, nb, ctx->num_cu);
+        fprintf(stderr, "[sdr] rx_fused<%d,%d,%d,%d,%d,%d,%d>: %d threads/WG, %d WG/CU, %d CUs\n", LOG2N, MI, MQ, int(FULL), int(EQ), int(HARDONLY), int(NOWGT), S::WG_THREADS, nb, ctx->num_cu);
     }
     const unsigned long long blocks = (n_groups + per_wg - 1) / per_wg;
     if (blocks > 0x7FFFFFFFull) return fail(SDR_ERR_UNSUPPORTED, "batch too large for one launch");

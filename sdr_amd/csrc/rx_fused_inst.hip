@@ -15,16 +15,7 @@ namespace sdr {
 
 // mod = 0: FFT only.  variant bit 0: per-subcarrier taps / weights are given (prefetching
 // instantiation); bit 1: every output optional (hard bits, bins, counters); 4: hard bits only;
-// 5 / 6 (builds with -DSDR_GROUP_VARIANTS only, n_fft 1024): variant 1 with seven / two symbols of
-// one tap set per workgroup, taps shared through LDS -- a measured dead end kept as an experiment.
-#if defined(SDR_GROUP_VARIANTS) && SDR_LOG2N == 10
-#define SDR_GROUP_CASES(MI, MQ)                                                                    \
-        case 5: return launch_rx_fused<SDR_LOG2N, MI, MQ, false, true, false, 7>(ctx, p);          \
-        case 6: return launch_rx_fused<SDR_LOG2N, MI, MQ, false, true, false, 2>(ctx, p);
-#else
-#define SDR_GROUP_CASES(MI, MQ)
-#endif
-
+// 9: LLRs only, taps without a weight array (no weight loads: scalar weight, or derived from the taps).
 int SDR_CAT(rx_fused_dispatch_, SDR_LOG2N)(sdr_ctx* ctx, const RxParams& p, int mod, int variant)
 {
     constexpr int L = SDR_LOG2N;
@@ -32,9 +23,9 @@ int SDR_CAT(rx_fused_dispatch_, SDR_LOG2N)(sdr_ctx* ctx, const RxParams& p, int 
     switch (variant) {                                                         \
         case 0: return launch_rx_fused<L, MI, MQ, false, false>(ctx, p);       \
         case 1: return launch_rx_fused<L, MI, MQ, false, true>(ctx, p);        \
-        SDR_GROUP_CASES(MI, MQ)                                                \
+        case 9: return launch_rx_fused<L, MI, MQ, false, true, false, true>(ctx, p); \
         case 2: return launch_rx_fused<L, MI, MQ, true, false>(ctx, p);        \
-        case 4: return launch_rx_fused<L, MI, MQ, false, false, true>(ctx, p); \
+        case 4: return launch_rx_fused<L, MI, MQ, false, false, true>(ctx, p);        \
         default: return launch_rx_fused<L, MI, MQ, true, true>(ctx, p);        \
     }
     switch (mod) {
@@ -42,6 +33,7 @@ int SDR_CAT(rx_fused_dispatch_, SDR_LOG2N)(sdr_ctx* ctx, const RxParams& p, int 
         case 1:                                                       // BPSK: the LLR-only variants, or the every-output ones (no hard-bits-only form)
             if (variant == 0) return launch_rx_fused<L, 1, 0, false, false>(ctx, p);
             if (variant == 1) return launch_rx_fused<L, 1, 0, false, true>(ctx, p);
+            if (variant == 9) return launch_rx_fused<L, 1, 0, false, true, false, true>(ctx, p);
             return (variant & 1) ? launch_rx_fused<L, 1, 0, true, true>(ctx, p) : launch_rx_fused<L, 1, 0, true, false>(ctx, p);
         case 2: SDR_RX_CASE(1, 1)
         case 4: SDR_RX_CASE(2, 2)

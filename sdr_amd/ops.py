@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 from . import capi
-from .capi import POINT_HARD_ONLY, SWEEP_ZERO_COUNTERS, ChainArgs, DemodArgs, LinkArgs, SweepArgs, SweepPoint, check
+from .capi import DEMOD_WEIGHT_FROM_TAPS, POINT_HARD_ONLY, SWEEP_ZERO_COUNTERS, ChainArgs, DemodArgs, LinkArgs, SweepArgs, SweepPoint, check
 
 MODS = {"bpsk": 1, "qpsk": 2, "16qam": 4, "64qam": 6, "256qam": 8, "1024qam": 10}
 
@@ -173,8 +173,9 @@ class Context:
               llr_weight=1.0, sym_per_set: int = 0, want_llr: bool = True, want_hard: bool = False,
               want_fft: bool = False, ref_hard: Optional[torch.Tensor] = None, counters: Optional[torch.Tensor] = None,
               out_llr: Optional[torch.Tensor] = None, out_hard: Optional[torch.Tensor] = None,
-              out_fft: Optional[torch.Tensor] = None, noalloc: bool = False) -> DemodResult:
-        """noalloc=True calls sdr_ofdm_demod_noalloc_c32 (static device scratch, no hipMalloc in the
+              out_fft: Optional[torch.Tensor] = None, noalloc: bool = False, weight_from_taps: bool = False) -> DemodResult:
+        """weight_from_taps=True (taps given, llr_weight a scalar): SDR_DEMOD_WEIGHT_FROM_TAPS, w_k = llr_weight / |G_k|^2
+        formed in the kernel.  noalloc=True calls sdr_ofdm_demod_noalloc_c32 (static device scratch, no hipMalloc in the
         library; pass every out_* tensor so that torch allocates nothing either)."""
         bps = mod_bits(mod)
         _need(rx, torch.complex64, "rx")
@@ -218,6 +219,8 @@ class Context:
             _need(counters, torch.int64, "counters", 8)
             a.d_ref_hard = ref_hard.data_ptr()
             a.d_counters = counters.data_ptr()
+        if weight_from_taps:
+            a.flags = DEMOD_WEIGHT_FROM_TAPS
         fn = self.lib.sdr_ofdm_demod_noalloc_c32 if noalloc else self.lib.sdr_ofdm_demod_c32
         check(fn(self._h, ctypes.byref(a)))
         return DemodResult(llr, hard, fft)

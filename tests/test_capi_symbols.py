@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header():
     from sdr_amd import capi
-    assert ctypes.sizeof(capi.DemodArgs) == 96
+    assert ctypes.sizeof(capi.DemodArgs) == 104 and capi.DemodArgs.flags.offset == 96      # 96 = the round-2 layout, still accepted
     assert ctypes.sizeof(capi.LinkArgs) == 88
     assert ctypes.sizeof(capi.PipeConfig) == 56
     assert ctypes.sizeof(capi.PipeResult) == 48

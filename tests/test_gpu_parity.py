@@ -437,6 +437,67 @@ def test_demod_llr_only_with_taps_or_weights(ctx, oracle, n, cp, bps, per, which
     assert same(out.llr.cpu().numpy(), ref["llr"])
 
 
+@pytest.mark.parametrize("n,cp,bps,per", [(64, 16, 2, 7), (128, 32, 6, 3), (256, 64, 8, 14), (512, 128, 4, 5), (1024, 256, 6, 14), (1024, 256, 4, 14), (1024, 256, 10, 2),
+                                          (2048, 512, 6, 14), (2048, 512, 2, 7), (4096, 1024, 8, 14), (4096, 1024, 1, 7), (8192, 2048, 6, 14), (8192, 2048, 1, 5),
+                                          (1024, 255, 6, 14), (16384, 4096, 4, 2), (32, 8, 4, 3)])
+def test_demod_weight_from_taps(ctx, oracle, n, cp, bps, per):
+    """SDR_DEMOD_WEIGHT_FROM_TAPS: taps without a weight array, w_k = llr_weight0 / |G_k|^2 formed in the kernel (one
+    correctly rounded division per bin).  The LLR-only request takes the instantiation that issues no weight load at all,
+    the every-output request the ordinary one, an odd prefix or an untuned size the generic engines: all equal to the
+    oracle's definition bit for bit, and within 1e-6 of the two-array form (zero-forcing weights norm^2 |H|^2 / N0)."""
+    from sdr_amd.link import noise_sigma, grid_energy
+    rng = np.random.default_rng(3 * n + bps)
+    n_sym = 31 if n <= 2048 else 9
+    n_sets = (n_sym + per - 1) // per
+    h = (rand_c(rng, (n_sets, n)) * np.float32(np.sqrt(0.5))).astype(np.complex64)
+    h[np.abs(h) < 0.1] += np.float32(0.3)
+    rx, bits = oracle.link_generate(n, cp, bps, 17, 0, n_sym, np.float32(noise_sigma(n, bps, 25.0)), chan=h, sym_per_set=per)
+    inv_n0 = 20.0
+    taps, wgt = oracle.zf_taps(bps, h, inv_n0)
+    w0 = np.float32(np.float32(1.0 / grid_energy(bps)) * np.float32(inv_n0))
+    ref = oracle.demod(rx, n, cp, bps, eq=taps, weight=w0, sym_per_set=per, weight_from_taps=True)
+    d_rx, d_taps = dev(rx), dev(taps.ravel())
+    out = ctx.demod(d_rx, n, cp, bps, eq=d_taps, llr_weight=float(w0), sym_per_set=per, weight_from_taps=True)
+    assert same(out.llr.cpu().numpy(), ref["llr"])
+    two = oracle.demod(rx, n, cp, bps, eq=taps, weight=wgt, sym_per_set=per, want_fft=False, want_hard=False)
+    assert rel_err(ref["llr"], two["llr"]) < 2e-6                       # the same weights up to rounding
+    cnt = torch.zeros(8, dtype=torch.int64, device="cuda")
+    full = ctx.demod(d_rx, n, cp, bps, eq=d_taps, llr_weight=float(w0), sym_per_set=per, weight_from_taps=True, want_hard=True, want_fft=True,
+                     ref_hard=dev(bits), counters=cnt)
+    assert same(full.llr.cpu().numpy(), ref["llr"]) and same(full.hard.cpu().numpy(), ref["hard"]) and same(full.fft.cpu().numpy(), ref["fft"])
+    l = ref["llr"].reshape(-1, bps)
+    q = np.minimum(np.abs(l) * np.float32(1024.0), np.float32(1073741824.0)).astype(np.int64)
+    c = cnt.cpu().numpy()
+    assert c[0] == oracle.count_bit_errors(ref["hard"], bits) and c[5] == int(q.sum())
+    # taps alone WITHOUT the flag: the scalar weight (and no weight load either)
+    plain = oracle.demod(rx, n, cp, bps, eq=taps, weight=w0, sym_per_set=per, want_fft=False, want_hard=False)
+    assert same(ctx.demod(d_rx, n, cp, bps, eq=d_taps, llr_weight=float(w0), sym_per_set=per).llr.cpu().numpy(), plain["llr"])
+
+
+def test_demod_args_flags_and_round2_layout(ctx, oracle):
+    """The 96-byte round-2 sdr_demod_args (no `flags`) is still accepted; the flag needs taps and no weight array."""
+    import ctypes
+    from sdr_amd import capi
+    rx, _ = oracle.link_generate(64, 16, 4, 3, 0, 4, 0.01)
+    ref = oracle.demod(rx, 64, 16, 4, weight=2.0, want_fft=False, want_hard=False)
+    d_rx = dev(rx)
+    llr = torch.zeros(4 * 64 * 4, dtype=torch.float32, device="cuda")
+    a = capi.DemodArgs()
+    a.struct_size = 96
+    a.n_fft, a.cp, a.mod, a.n_sym, a.llr_weight0 = 64, 16, 4, 4, 2.0
+    a.d_rx, a.d_llr = d_rx.data_ptr(), llr.data_ptr()
+    a.flags = 0xFFFF                                                      # behind the declared size: must not be read
+    assert ctx.lib.sdr_ofdm_demod_c32(ctx._h, ctypes.byref(a)) == capi.SDR_OK
+    torch.cuda.synchronize()
+    assert same(llr.cpu().numpy().reshape(ref["llr"].shape), ref["llr"])
+    a.struct_size = ctypes.sizeof(capi.DemodArgs)
+    assert ctx.lib.sdr_ofdm_demod_c32(ctx._h, ctypes.byref(a)) == capi.SDR_ERR_INVALID and "flags" in capi.last_error()
+    a.flags = capi.DEMOD_WEIGHT_FROM_TAPS                                 # no taps given
+    assert ctx.lib.sdr_ofdm_demod_c32(ctx._h, ctypes.byref(a)) == capi.SDR_ERR_INVALID and "d_eq" in capi.last_error()
+    a.struct_size = 100
+    assert ctx.lib.sdr_ofdm_demod_c32(ctx._h, ctypes.byref(a)) == capi.SDR_ERR_INVALID and "struct_size" in capi.last_error()
+
+
 @pytest.mark.parametrize("n,cp,bps", [(64, 16, 2), (128, 32, 6), (512, 128, 8), (1024, 256, 4), (1024, 256, 6), (2048, 512, 6), (4096, 1024, 8),
                                       (8192, 2048, 4), (1024, 256, 10), (256, 64, 1)])
 def test_hard_decisions_only(ctx, oracle, n, cp, bps):

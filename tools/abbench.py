@@ -2,7 +2,8 @@
 """Same-buffer A/B of two builds of libsdr_amd.so: both libraries are loaded into ONE process and time the
 receive kernel alternately on the SAME tensors, so that neither the box nor the placement of the buffers
 (profiles/r2_eq_placement_lottery.txt) can tell them apart.
-usage: abbench.py libA.so libB.so --cases n_fft:bps[:eq][:hard][:nollr][:fft] | n_fft:bins ...   (prints % of 8 TB/s for A, B, A - B)"""
+usage: abbench.py libA.so libB.so --cases n_fft:bps[:eq|:taps][:hard][:cnt][:nollr][:fft] | n_fft:bins ...   (prints % of 8 TB/s for A, B, A - B;
+taps = equaliser taps without a weight array (scalar weight), wft = the same with SDR_DEMOD_WEIGHT_FROM_TAPS, cnt = counters against reference bits)"""
 import argparse
 import ctypes
 import os
@@ -36,7 +37,9 @@ def main():
         n = int(parts[0])
         bins_only = parts[1] == "bins"                      # ofdm::rx: strip the prefix, transform, bins out
         bps = 2 if bins_only else int(parts[1])
-        with_eq, with_hard, no_llr, with_fft = "eq" in parts[2:], "hard" in parts[2:], "nollr" in parts[2:] or bins_only, "fft" in parts[2:]
+        wft = "wft" in parts[2:]
+        with_eq, with_hard, no_llr, with_fft = "eq" in parts[2:] or "taps" in parts[2:] or wft, "hard" in parts[2:], "nollr" in parts[2:] or bins_only, "fft" in parts[2:]
+        taps_only, with_cnt = "taps" in parts[2:] or wft, "cnt" in parts[2:]
         cp = n // 4
         bytes_sym = 8 * n + (0 if no_llr else 4 * n * bps) + (n * bps // 8 if with_hard else 0) + (8 * n if with_fft or bins_only else 0)
         n_sym = max(1024, min(1 << 20, (8 << 30) // (bytes_sym + 8 * cp)))
@@ -47,7 +50,11 @@ def main():
             per = 14
             n_sets = (n_sym + per - 1) // per
             eq = torch.randn((n_sets, n * 2), dtype=torch.float32, device="cuda", generator=g).view(torch.complex64)
-            wgt = torch.rand((n_sets, n), dtype=torch.float32, device="cuda", generator=g)
+            wgt = None if taps_only else torch.rand((n_sets, n), dtype=torch.float32, device="cuda", generator=g)
+        ref = cnt = None
+        if with_cnt:
+            ref = torch.randint(0, 256, (n_sym * n * bps // 8,), dtype=torch.uint8, device="cuda", generator=g)
+            cnt = torch.zeros(8, dtype=torch.int64, device="cuda")
         out = None if no_llr else torch.empty((n_sym, n, bps), dtype=torch.float32, device="cuda")
         hard = torch.empty(n_sym * n * bps // 8, dtype=torch.uint8, device="cuda") if with_hard else None
         bins = torch.empty((n_sym, n), dtype=torch.complex64, device="cuda") if with_fft or bins_only else None
@@ -56,7 +63,8 @@ def main():
             if bins_only:
                 step = lambda: capi.check(c.lib.sdr_ofdm_rx_c32(c._h, rx.data_ptr(), n, cp, n_sym, bins.data_ptr()))
             else:
-                step = lambda: c.demod(rx, n, cp, bps, eq=eq, llr_weight=(wgt if wgt is not None else 1.5), sym_per_set=per, out_llr=out, want_llr=not no_llr, out_hard=hard, out_fft=bins)
+                step = lambda: c.demod(rx, n, cp, bps, eq=eq, llr_weight=(wgt if wgt is not None else 1.5), sym_per_set=per, out_llr=out, want_llr=not no_llr, out_hard=hard, out_fft=bins,
+                                       ref_hard=ref, counters=cnt, weight_from_taps=wft)
             for _ in range(3):
                 step()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -74,7 +82,7 @@ def main():
             rb.append(rate(cb))
         ma, mb = sorted(ra)[len(ra) // 2], sorted(rb)[len(rb) // 2]
         print(f"case {case:>14s}  A {ma:5.1f}  B {mb:5.1f}  A-B {ma - mb:+5.1f}   (A {' '.join(f'{v:.1f}' for v in ra)} | B {' '.join(f'{v:.1f}' for v in rb)})", flush=True)
-        del rx, eq, wgt, out, hard, bins
+        del rx, eq, wgt, out, hard, bins, ref, cnt
         torch.cuda.empty_cache()
 
 
