@@ -33,22 +33,35 @@ WORKLOADS = {
 }
 
 
-TRAFFIC_FILES = ("r2_traffic.json", "r1_traffic.json")      # newest first
+TRAFFIC_FILES = ("r3_traffic.json", "r2_traffic.json", "r1_traffic.json")      # newest first
+
+
+def kernel_source_fingerprint():
+    """sha256 over the kernel sources (sdr_amd/csrc/*.hpp, *.hip): written into profiles/rN_traffic.json by the PMC
+    passes and compared here, so that the bench line says whether its `traffic` figure was measured on THIS build."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for p in sorted(glob.glob(os.path.join(ROOT, "sdr_amd", "csrc", "*.h*"))):
+        h.update(os.path.basename(p).encode())
+        h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def measured_traffic(workload, n_sym):
-    """(HBM bytes per launch, file) from the committed PMC passes (profiles/r2_traffic.json, else round
-    1's: FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 runs of this script by
-    tools/profile_bench.sh, gfx950 correction applied); (None, None) when no pass covers the workload."""
+    """(HBM bytes per launch, file, same build?) from the committed PMC passes (profiles/r3_traffic.json, else an
+    earlier round's: FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 runs of this script by
+    tools/profile_bench.sh, gfx950 correction applied); (None, None, None) when no pass covers the workload."""
     for name in TRAFFIC_FILES:
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
-                k = json.load(f)["kernels"].get(workload)
+                d = json.load(f)
+            k = d["kernels"].get(workload)
             if k is not None:
-                return k["hbm_bytes_per_symbol"] * n_sym, name
+                return k["hbm_bytes_per_symbol"] * n_sym, name, d.get("kernel_source_fingerprint") == kernel_source_fingerprint()
         except (OSError, ValueError, KeyError):
             continue
-    return None, None
+    return None, None, None
 
 
 def algorithmic_bytes_per_symbol(n_fft, bps):
@@ -163,7 +176,7 @@ def time_workload(ctx, torch, group, name, steps, warmup, n_sym_override=None):
     # 8(d) leaves them out of the algorithmic count ("amortised / L2-resident"), so `frac` does too;
     # the bytes are real (2.7 % at 14 symbols per set) and are reported beside it.
     tap_bytes_sym = (12.0 * n_fft / per) if with_eq else 0.0
-    traffic, traffic_file = measured_traffic(name, n_sym)
+    traffic, traffic_file, traffic_same_build = measured_traffic(name, n_sym)
     res = {
         "n_fft": n_fft, "cp": cp, "bps": bps, "n_sym": n_sym, "elapsed": elapsed, "with_eq": with_eq,
         "tap_bytes_per_symbol": tap_bytes_sym, "frac_incl_taps": (b_sym + tap_bytes_sym) * n_sym / avg_launch_s / 1e9 / HBM_PEAK_GBS,
@@ -171,7 +184,8 @@ def time_workload(ctx, torch, group, name, steps, warmup, n_sym_override=None):
         "copy_shape_gbs": copy_gbs,
         "per_launch": launch_stats(launch_ms, b_sym * n_sym),
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "traffic_unit": f"bytes per launch (rocprofv3 PMC, separate passes of an earlier build of the same kernel; profiles/{traffic_file})",
+                     "traffic": traffic, "traffic_unit": f"bytes per launch (rocprofv3 PMC, separate passes; profiles/{traffic_file})",
+                     "traffic_measured_on_this_build": traffic_same_build,
                      "algorithmic_bytes_per_launch": b_sym * n_sym, "bytes_per_symbol": b_sym, "symbols_per_launch": n_sym, "avg_launch_ms": avg_launch_s * 1e3},
     }
     res["buffers"] = {k: hex(v.data_ptr()) for k, v in (("rx", rx), ("llr", llr), ("eq", eq), ("wgt", wgt)) if v is not None}      # placement, for the record

@@ -114,3 +114,23 @@ def test_product_does_not_touch_the_oracle():
                 if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp", "Makefile")):
                     text = open(os.path.join(dirpath, f), errors="replace").read()
                     assert "oracle" not in text.lower(), os.path.join(dirpath, f)
+
+
+def test_multi_gpu_library_exports_every_declared_symbol():
+    """libsdr_amd_multi.so (the native multi-GPU driver, links RCCL) loads without a GPU and exports what
+    include/sdr_amd_multi.h declares; without a device its constructor fails with an error value."""
+    text = open(os.path.join(ROOT, "include", "sdr_amd_multi.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = sorted(set(re.findall(r"\b(sdr_multi_[a-z0-9_]+)\s*\(", text)))
+    assert len(names) >= 8
+    lib = ctypes.CDLL(os.path.join(ROOT, "sdr_amd", "lib", "libsdr_amd_multi.so"))
+    for n in names:
+        assert hasattr(lib, n), f"libsdr_amd_multi.so does not export {n}"
+    import torch
+    if not torch.cuda.is_available():
+        lib.sdr_multi_last_error.restype = ctypes.c_char_p
+        h = ctypes.c_void_p()
+        dev = (ctypes.c_int * 1)(0)
+        assert lib.sdr_multi_create(dev, 1, ctypes.byref(h)) != 0 and not h.value
+        assert b"GPU 0" in lib.sdr_multi_last_error()
+        assert lib.sdr_multi_create(dev, 0, ctypes.byref(h)) != 0

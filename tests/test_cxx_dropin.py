@@ -11,10 +11,11 @@ EXE = os.path.join(ROOT, "tests", "cxx", "dropin_test")
 
 HOST_EXE = os.path.join(ROOT, "tests", "cxx", "host_test")
 DEMO_EXE = os.path.join(ROOT, "tests", "cxx", "ofdm_demo")
+MULTI_EXE = os.path.join(ROOT, "tests", "cxx", "ber_sweep_multi")
 
 
 def _build():
-    if not all(os.path.exists(e) for e in (EXE, HOST_EXE, DEMO_EXE)):
+    if not all(os.path.exists(e) for e in (EXE, HOST_EXE, DEMO_EXE, MULTI_EXE)):
         subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "cxx")], check=True, capture_output=True)
 
 
@@ -61,3 +62,32 @@ def test_headless_demo_shows_the_payload(tmp_path):
     assert len(t_csv.read_text().splitlines()) == 513          # header + the 512-sample window
     pts = c_csv.read_text().splitlines()[1:]
     assert len(pts) == 8                                        # 4 bytes = 8 16-QAM points per tick
+
+
+@pytest.mark.gpu
+def test_native_multi_gpu_sweep_equals_python_sweep(ctx):
+    """examples/ber_sweep_multi.cpp: the Eb/N0 sweep driven from C++ through libsdr_amd_multi.so (one context and one
+    host thread per GPU, ncclCommInitAll, one ncclAllReduce of the counters) on the GPUs of this box.  Same frame plan
+    and random streams as ber_sweep.py, so its counters equal those of the Python sweep bit for bit."""
+    import json
+    import numpy as np
+    from sdr_amd import link
+    _build()
+    p = subprocess.run([MULTI_EXE, "--bits", "6e7", "--n-fft", "512", "--cp", "128", "--mods", "2", "4", "6", "--step-db", "5", "--seed", "5"],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    ebn0 = {2: [0.0, 5.0, 10.0], 4: [0.0, 5.0, 10.0, 15.0], 6: [0.0, 5.0, 10.0, 15.0, 20.0]}
+    pts = link.plan_sweep([2, 4, 6], ebn0, 512, 6e7)
+    want = ctx.link_sweep(512, 128, 5, link.rank_points(pts, 512, 0, 1)).cpu().numpy()
+    assert line["points"] == len(pts) and line["n_gpus"] >= 1
+    assert np.array_equal(np.array(line["counters"], dtype=np.int64), want)
+    assert line["checksum_bit_errors"] == int(want[:, 0].sum()) > 0 and "ncclAllReduce" in line["collective"]
+    # the faded link (configs[2] shape) the same way: counters equal the one-GPU sdr_link_chain_c32 run
+    n_sym = 14 * 300
+    p = subprocess.run([MULTI_EXE, "--chain", str(n_sym)], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    chain = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    cnt, _, _ = ctx.link_chain(2048, 512, 6, 3, 0, n_sym, ((1 << 18) // 14) * 14, 14, link.noise_sigma(2048, 6, 18.0), 6 * 10 ** 1.8, want_llr=True)
+    k = cnt.cpu().tolist()
+    assert (chain["bit_errors"], chain["bits"], chain["ofdm_symbols"]) == (k[0], k[1], k[4]) and k[0] > 0
