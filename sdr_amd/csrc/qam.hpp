@@ -194,25 +194,23 @@ __device__ inline unsigned nearest_fast(T ur, T ui)
     return nearest_by_scan<T, MI, MQ>(ur, ui);
 }
 
-// One axis of the margin slicer: binary level index, distance of the slicer coordinate from the
-// centre of its decision cell, and how far beyond the grid the coordinate lies (both in slicer
-// units: one unit = two grid units).
+// One axis of the margin slicer, on the HALF coordinate s = v / 2 (v = point * inorm, the scan's coordinate; the
+// halving is exact, so s may be formed as re * (inorm / 2) in one product): binary level index and the distance of the
+// slicer coordinate t = s + (L - 1) / 2 from the centre of its decision cell (slicer units: one unit = two grid
+// units).  fl(s + (L - 1) / 2) is the value the two-step form fl(fl(v + (L - 1)) * 0.5) had.
 template <typename T, int M>
-__device__ inline void axis_slice(T v, unsigned& bin, T& miss, T& beyond)
+__device__ inline void axis_slice(T s, T& level, T& miss)
 {
     if constexpr (M == 0) {
-        bin = 0u;
+        level = T(0);
         miss = T(0);
-        beyond = v * T(0.5);
     } else {
         constexpr int L = 1 << M;
-        const T t = (v + T(L - 1)) * T(0.5);
-        T tc = t > T(-0.25) ? t : T(-0.25);                       // NaN -> -0.25, and `beyond` turns NaN
+        const T t = s + T(L - 1) * T(0.5);
+        T tc = t > T(-0.25) ? t : T(-0.25);                       // NaN -> -0.25 (the reach test below sees the NaN)
         tc = tc < T(L) - T(0.75) ? tc : T(L) - T(0.75);
-        const T a = rint(tc);                                     // 0 ... L-1
-        miss = tc - a;
-        beyond = t - tc;
-        bin = static_cast<unsigned>(static_cast<int>(a));
+        level = rint(tc);                                         // 0 ... L-1
+        miss = tc - level;
     }
 }
 
@@ -220,39 +218,63 @@ __device__ inline void axis_slice(T v, unsigned& bin, T& miss, T& beyond)
 #define SDR_MARGIN_OFF 0     // 1: experiment, every hard decision takes the three-point test
 #endif
 
-// nearest() from a plain slicer whenever the point is CLEARLY inside one decision cell, about half
-// the instructions of the three-point test.  (A, B) is accepted when, on both axes, the slicer
-// coordinate t = (v + L - 1) / 2 is at most 1/2 - 2^-14 from the cell centre and at most 14 beyond
-// the outer cells (which extend outwards).  Why this is the scan's answer, float or double:
-//   * t carries an error below 2^-19 (|v + L - 1| < 128), so v is at most 1 - 2^-13 + 2^-18 from level
+// nearest() from a plain slicer whenever the point is CLEARLY inside one decision cell, about a third
+// of the instructions of the three-point test.  (A, B) is accepted when, on both axes, the slicer
+// coordinate t is at most 1/2 - 2^-14 from the cell centre (the outer cells extend outwards) and the point's
+// reach |s_I| + |s_Q| is at most (L - 1) / 2 + 31 (a NaN on either axis fails this test: the sum, unlike a maximum,
+// does not lose it).  Why this is the scan's answer, float or double:
+//   * |t| <= |s| + (L - 1) / 2 < 64, so t carries an error below 2^-19 and v is at most 1 - 2^-13 + 2^-18 from level
 //     A and at least 1 + 2^-13 - 2^-18 from every other level of that axis; beyond the grid the
 //     nearest other level is 2 further than the edge level;
-//   * the scan's rounded axis distances are monotonic in |v - level|, so every other level's
-//     differs from A's by at least that of the neighbour: more than 2^-12 inside, more than 4
-//     outside;
-//   * every squared distance is below 31^2, every sum m below 2^11 where one ulp is 2^-13: a point
-//     that differs from (A, B) on either axis has an exact sum at least 2^-12 larger and therefore
-//     a strictly larger rounded one.  m is finite, so the strict '<' scan returns (A, B).
+//   * the scan's rounded axis distances are monotonic in |v - level|, so every other level's squared distance
+//     exceeds A's by at least that of the neighbour: 4 (1 - 2^-5) 2^-13 > 1.9 * 2^-12 inside, more than 4 outside;
+//   * the reach bound leaves a coordinate at most 30.5 slicer units beyond the outer cell of its axis (and the two
+//     excesses together no more): the distance to the own cell's level is at most 62 grid units on one axis with at
+//     most 1 + 2^-13 on the other (the sum of squares is convex, so the split excess is smaller), i.e. every sum m is
+//     below 2^12, where one ulp is at most 2^-12: a point that differs from (A, B) on either axis has an exact sum at
+//     least 1.9 ulp larger and therefore a strictly larger rounded one.  m is finite, so the strict '<' scan returns
+//     (A, B).
 // Everything else -- one point in 4000 of a uniform spread, NaN, far outliers -- takes the
 // three-point test (and from there, rarely, the scan).
 template <typename T, int MI, int MQ>
 __device__ __noinline__ unsigned nearest_checked(T ur, T ui) { return nearest_fast<T, MI, MQ>(ur, ui); }
 
 template <typename T, int MI, int MQ>
-__device__ inline unsigned nearest_margin(T ur, T ui)
-{
-    if constexpr (SDR_MARGIN_OFF) return nearest_fast<T, MI, MQ>(ur, ui);
-    unsigned bi, bq;
-    T mi, mq, oi, oq;
-    axis_slice<T, MI>(ur, bi, mi, oi);
-    axis_slice<T, MQ>(ui, bq, mq, oq);
-    const T miss = fabs(mi) > fabs(mq) ? fabs(mi) : fabs(mq);
-    const bool sure = (miss <= T(0.5) - T(0.00006103515625)) && (fabs(oi) <= T(14)) && (fabs(oq) <= T(14));
-    if (sure) {
-        const unsigned w = (bi << MQ) | bq;                        // both binary indices; Gray-code them in one go
+struct MarginSlicer {
+    static constexpr int LMAX = 1 << (MI > MQ ? MI : MQ);
+    static __device__ __forceinline__ T reach_limit() { return T(LMAX - 1) * T(0.5) + T(31); }
+    static __device__ __forceinline__ T miss_limit() { return T(0.5) - T(0.00006103515625); }
+    // slicer proposal for the half coordinates (si, sq): both binary level indices as one word (I above Q, not yet
+    // Gray-coded), the larger distance from a cell centre and the reach
+    static __device__ __forceinline__ unsigned propose(T si, T sq, T& miss, T& reach)
+    {
+        T ai, aq, mi, mq;
+        axis_slice<T, MI>(si, ai, mi);
+        axis_slice<T, MQ>(sq, aq, mq);
+        miss = fmax(fabs(mi), fabs(mq));                           // never NaN (the clamp)
+        reach = fabs(si) + fabs(sq);                               // NaN if either is
+        const unsigned bi = static_cast<unsigned>(static_cast<int>(ai));
+        if constexpr (MQ == 0) return bi;
+        else return (bi << MQ) | static_cast<unsigned>(static_cast<int>(aq));
+    }
+    static __device__ __forceinline__ bool sure(T miss, T reach) { return (miss <= miss_limit()) && (reach <= reach_limit()); }
+    // Gray-codes both axes of the proposal in one go
+    static __device__ __forceinline__ unsigned gray(unsigned w)
+    {
         constexpr unsigned kKeep = MQ > 0 ? ~(1u << (MQ - 1)) : ~0u;   // I's lowest bit must not leak into Q's highest
         return w ^ ((w >> 1) & kKeep);
     }
+};
+
+// (si, sq) = half coordinates (exactly (ur, ui) / 2); (ur, ui) only feed the out-of-line test
+template <typename T, int MI, int MQ>
+__device__ inline unsigned nearest_margin(T si, T sq, T ur, T ui)
+{
+    if constexpr (SDR_MARGIN_OFF) return nearest_fast<T, MI, MQ>(ur, ui);
+    using MS = MarginSlicer<T, MI, MQ>;
+    T miss, reach;
+    const unsigned w = MS::propose(si, sq, miss, reach);
+    if (MS::sure(miss, reach)) return MS::gray(w);
     return nearest_checked<T, MI, MQ>(ur, ui);
 }
 
@@ -260,12 +282,22 @@ __device__ inline unsigned nearest_margin(T ur, T ui)
 template <typename T, int MI, int MQ, bool WANT_LLR, bool WANT_IDX>
 __device__ inline unsigned demap_point(T re, T im, T inorm, T w, T* llr)
 {
+    if constexpr (!WANT_LLR) {
+        // hard decision alone: no need for every distance (4-level axes gain nothing from it); the half coordinates
+        // come from one product each (re * (inorm / 2) is exactly (re * inorm) / 2), the scan's own coordinates are
+        // formed only where the out-of-line test wants them
+        if constexpr (WANT_IDX && (MI >= SDR_FAST_FROM || MQ >= SDR_FAST_FROM)) {
+            if constexpr (SDR_MARGIN_OFF) return nearest_fast<T, MI, MQ>(re * inorm, im * inorm);
+            using MS = MarginSlicer<T, MI, MQ>;
+            const T half = inorm * T(0.5);
+            T miss, reach;
+            const unsigned w2 = MS::propose(re * half, im * half, miss, reach);
+            if (MS::sure(miss, reach)) return MS::gray(w2);
+            return nearest_checked<T, MI, MQ>(re * inorm, im * inorm);
+        }
+    }
     const T ur = re * inorm;
     const T ui = im * inorm;
-    if constexpr (!WANT_LLR) {
-        // hard decision alone: no need for every distance (4-level axes gain nothing from it)
-        if constexpr (WANT_IDX && (MI >= SDR_FAST_FROM || MQ >= SDR_FAST_FROM)) return nearest_margin<T, MI, MQ>(ur, ui);
-    }
     T dx[1 << MI];
     T dy[1 << MQ];
     axis_distances<T, MI>(ur, dx);
@@ -277,7 +309,7 @@ __device__ inline unsigned demap_point(T re, T im, T inorm, T w, T* llr)
     unsigned idx = 0;
     if constexpr (WANT_IDX) {
         // even with every distance at hand the three-point test is cheaper than the scan from 8 levels up
-        if constexpr (MI >= SDR_FAST_FROM || MQ >= SDR_FAST_FROM) idx = nearest_margin<T, MI, MQ>(ur, ui);
+        if constexpr (MI >= SDR_FAST_FROM || MQ >= SDR_FAST_FROM) idx = nearest_margin<T, MI, MQ>(ur * T(0.5), ui * T(0.5), ur, ui);
         else idx = nearest_from_distances<T, MI, MQ>(dx, dy);
     }
     return idx;

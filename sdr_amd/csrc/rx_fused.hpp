@@ -179,11 +179,20 @@ struct PlanOps {
 // table is the conjugate of the forward one except for the sign of the zero imaginary part of
 // its W = 1 entries (checked on the host tables), so an inverse transform run this way on the
 // forward table can differ from the true one only in the sign of exact zeros.
-template <bool CONJ = false>
+// UNIT: the twiddle is the recurrence's start value (1, +0) (lib/inc/fft.hpp:122-123; butterfly j = 0 of every block),
+// known at compile time in the first pass.  x * 1 is x, so only the products with the zero remain -- they are kept:
+// they carry the sign of the zero and turn an infinity or NaN into the NaN the reference gets.
+template <bool CONJ = false, bool UNIT = false>
 __device__ __forceinline__ void bfly(float2& even, float2& odd, const float2 w)
 {
     float tr, ti;
-    if constexpr (CONJ) {
+    if constexpr (UNIT && CONJ) {
+        tr = odd.x + odd.y * 0.0f;
+        ti = odd.y - odd.x * 0.0f;
+    } else if constexpr (UNIT) {
+        tr = odd.x - odd.y * 0.0f;
+        ti = odd.x * 0.0f + odd.y;
+    } else if constexpr (CONJ) {
         tr = odd.x * w.x + odd.y * w.y;
         ti = odd.y * w.x - odd.x * w.y;
     } else {
@@ -330,7 +339,7 @@ __device__ __forceinline__ void fft_run(float2 (&x)[PlanOps<LOG2N>::kE], unsigne
         static_for<E / 2>([&](auto H) {
             constexpr int m0 = O::insert_zero(H, bi), m1 = m0 | (1 << bi);
             constexpr int j = O::reg_pos(0, m0) & ((1 << c) - 1);
-            bfly<CONJ>(x[m0], x[m1], w.first[(1 << c) - 1 + j]);
+            bfly<CONJ, j == 0>(x[m0], x[m1], w.first[(1 << c) - 1 + j]);
         });
     });
     static_for<E>([&](auto M) { constexpr int m = M; *reinterpret_cast<float2*>(lds_data + a.wr0 + O::reg_addr(0, 0, m)) = x[m]; });
@@ -382,6 +391,31 @@ __device__ __forceinline__ void stream_store2(float* dst, float a, float b)
     sdr_v2f v = {a, b};
     __builtin_nontemporal_store(v, reinterpret_cast<sdr_v2f*>(dst));
 }
+
+
+// 16 / 8 bytes per lane through a buffer resource with an explicit cache policy (AUX: bit 0 = sc0, bit 1 = nt, bit 4 = sc1)
+typedef unsigned sdr_v4u __attribute__((ext_vector_type(4)));
+typedef unsigned sdr_v2u __attribute__((ext_vector_type(2)));
+template <int AUX>
+__device__ __forceinline__ float4 policy_load16(const void* base, unsigned bytes, unsigned off)
+{
+    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, static_cast<int>(bytes), 0x00020000);
+    const sdr_v4u v = __builtin_amdgcn_raw_buffer_load_b128(r, static_cast<int>(off), 0, AUX);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+template <int AUX>
+__device__ __forceinline__ float2 policy_load8(const void* base, unsigned bytes, unsigned off)
+{
+    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, static_cast<int>(bytes), 0x00020000);
+    const sdr_v2u v = __builtin_amdgcn_raw_buffer_load_b64(r, static_cast<int>(off), 0, AUX);
+    return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+}
+#ifndef SDR_TAP_AUX
+#define SDR_TAP_AUX -1
+#endif
+#ifndef SDR_SAMPLE_AUX
+#define SDR_SAMPLE_AUX -1
+#endif
 
 // LLR staging through LDS: per-lane chunk of C floats -> lane-contiguous vectors (coalesced stores)
 constexpr int stage_stride_bytes(int c) { return c == 6 ? 24 : c == 8 ? 48 : c == 12 ? 48 : c == 16 ? 80 : c == 20 ? 80 : c * 4; }
@@ -655,7 +689,9 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
             } else {
                 // register bit kR[0] is the group bit: adjacent input samples
                 float4 v;
-                if constexpr (S::NT_SAMPLES) {
+                if constexpr (SDR_SAMPLE_AUX >= 0 && SPW == 1 && EQ) {
+                    v = policy_load16<SDR_SAMPLE_AUX>(p.rx + s_ * in_stride + p.cp, N * 8, static_cast<unsigned>(in_thread + idx0) * 8u);
+                } else if constexpr (S::NT_SAMPLES) {
                     const sdr_v4f q = __builtin_nontemporal_load(reinterpret_cast<const sdr_v4f*>(src + idx0));
                     v = make_float4(q.x, q.y, q.z, q.w);
                 } else {
@@ -719,11 +755,15 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
                 constexpr int h = Hh;
                 const int k = O::reg_pos(LAST, h * GO_) | pos_last;
                 if constexpr (GO_ == 2) {
-                    const float4 v = *reinterpret_cast<const float4*>(eq_src + k);
+                    float4 v;
+                    if constexpr (SDR_TAP_AUX >= 0 && SPW == 1) v = policy_load16<SDR_TAP_AUX>(eq_src, N * 8, static_cast<unsigned>(k) * 8u);
+                    else v = *reinterpret_cast<const float4*>(eq_src + k);
                     eqv[h * 2] = make_float2(v.x, v.y);
                     eqv[h * 2 + 1] = make_float2(v.z, v.w);
                     if constexpr (!NOWGT) {
-                        const float2 u = *reinterpret_cast<const float2*>(wgt_src + k);
+                        float2 u;
+                        if constexpr (SDR_TAP_AUX >= 0 && SPW == 1) u = policy_load8<SDR_TAP_AUX>(wgt_src, N * 4, static_cast<unsigned>(k) * 4u);
+                        else u = *reinterpret_cast<const float2*>(wgt_src + k);
                         wv[h * 2] = u.x;
                         wv[h * 2 + 1] = u.y;
                     }
@@ -834,6 +874,80 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
                 });
             }
         }
+        // hard decisions of the symbol group, parked in lds_idx, leave as MSB-first words
+        [[maybe_unused]] auto pack_hard = [&]() {
+            if constexpr (HARD_PATH) if (HARDONLY || p.hard) {
+                __syncthreads();
+                constexpr int WORDS = N * BPS / 32;
+                constexpr int CNT = (32 + BPS - 1) / BPS + 1;
+                if (active) {
+                    uint32_t* out = reinterpret_cast<uint32_t*>(p.hard + bin0 * BPS / 8);
+                    for (int j = t; j < WORDS; j += TPS) {
+                        const int k0 = (32 * j) / BPS;
+                        const int off = 32 * j - k0 * BPS;
+                        unsigned long long acc = 0;
+#pragma unroll
+                        for (int i = 0; i < CNT; ++i) {
+                            const int kk = (k0 + i < N) ? k0 + i : N - 1;
+                            acc = (acc << BPS) | lds_idx[slot * N + kk];
+                        }
+                        const uint32_t word = static_cast<uint32_t>(acc >> (CNT * BPS - off - 32));
+                        out[j] = __builtin_bswap32(word);
+                    }
+                }
+            }
+        };
+        // Hard decisions alone from 16-QAM up: the margin slicer (qam.hpp) runs over ALL of the thread's bins as one
+        // branch-free block -- a per-point branch to the out-of-line test costs eight scalar instructions, two exec
+        // round trips and a scheduling barrier per point -- and keeps, per register group, the mask of lanes whose
+        // proposal was not clearly inside its cell (one v_cmp into a scalar pair).  Waves with any such lane (about one
+        // in four on noise: a point in 4000 is doubtful) then redo exactly those groups for exactly those lanes with the
+        // three-point test / scan and overwrite the parked decisions.
+        constexpr bool SLICE_BLOCK = HARDONLY && (MI >= SDR_FAST_FROM || MQ >= SDR_FAST_FROM) && !SDR_MARGIN_OFF;
+        if constexpr (SLICE_BLOCK) {
+            using MS = MarginSlicer<float, MI, MQ>;
+            constexpr int NG = E / GO;
+            const float half = p.inorm * 0.5f;
+            unsigned long long doubt[NG];
+            unsigned long long any = 0;
+            static_for<NG>([&](auto Hh) {
+                constexpr int h = Hh;
+                const int k = O::reg_pos(LAST, h * GO) | pos_last;
+                bool ok = true;
+                unsigned w[GO];
+                static_for<GO>([&](auto G) {
+                    constexpr int g = G;
+                    float miss, reach;
+                    w[g] = MS::propose(x[h * GO + g].x * half, x[h * GO + g].y * half, miss, reach);
+                    ok = ok && MS::sure(miss, reach);
+                });
+                if constexpr (GO == 2 && sizeof(idx_t) == 1) {
+                    // both points Gray-coded in one go: the bytes keep their order in LDS (little endian: bin k first)
+                    constexpr unsigned keep1 = 0x7fu & (MQ > 0 ? ~(1u << (MQ - 1)) : ~0u);
+                    const unsigned pair = w[0] | (w[1] << 8);
+                    const unsigned coded = pair ^ ((pair >> 1) & (keep1 | (keep1 << 8)));
+                    *reinterpret_cast<uint16_t*>(lds_idx + slot * N + k) = static_cast<uint16_t>(coded);
+                } else {
+                    static_for<GO>([&](auto G) { constexpr int g = G; lds_idx[slot * N + k + g] = static_cast<idx_t>(MS::gray(w[g])); });
+                }
+                doubt[h] = __ballot(!ok);
+                any |= doubt[h];
+            });
+            if (any) {                                                  // uniform over the wave
+                const unsigned long long me = 1ull << (tid & 63);
+                static_for<NG>([&](auto Hh) {
+                    constexpr int h = Hh;
+                    if (doubt[h] & me) {
+                        const int k = O::reg_pos(LAST, h * GO) | pos_last;
+                        static_for<GO>([&](auto G) {
+                            constexpr int g = G;
+                            lds_idx[slot * N + k + g] = static_cast<idx_t>(nearest_checked<float, MI, MQ>(x[h * GO + g].x * p.inorm, x[h * GO + g].y * p.inorm));
+                        });
+                    }
+                });
+            }
+            pack_hard();
+        } else
         if constexpr (DEMAP) {
             // EPILOGUE_TAPS: the taps of register group h + AHEAD are requested before group h
             // is worked on (the run-time branches on p.eq / p.wgt and the staging barriers end the compiler's scheduling
@@ -998,28 +1112,7 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
                     }
                 }
             });
-            if constexpr (HARD_PATH) {
-                if (HARDONLY || p.hard) {
-                    __syncthreads();
-                    constexpr int WORDS = N * BPS / 32;
-                    constexpr int CNT = (32 + BPS - 1) / BPS + 1;
-                    if (active) {
-                        uint32_t* out = reinterpret_cast<uint32_t*>(p.hard + bin0 * BPS / 8);
-                        for (int j = t; j < WORDS; j += TPS) {
-                            const int k0 = (32 * j) / BPS;
-                            const int off = 32 * j - k0 * BPS;
-                            unsigned long long acc = 0;
-#pragma unroll
-                            for (int i = 0; i < CNT; ++i) {
-                                const int kk = (k0 + i < N) ? k0 + i : N - 1;
-                                acc = (acc << BPS) | lds_idx[slot * N + kk];
-                            }
-                            const uint32_t word = static_cast<uint32_t>(acc >> (CNT * BPS - off - 32));
-                            out[j] = __builtin_bswap32(word);
-                        }
-                    }
-                }
-            }
+            if constexpr (HARD_PATH) pack_hard();
         }
     };
     process(grp_begin);

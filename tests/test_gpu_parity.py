@@ -206,7 +206,9 @@ def test_nearest_adversarial_points_bit_exact(ctx, oracle, bps, dt):
     inorm = np.sqrt(dt(2.0 * (levels * levels - 1) / 3.0)) if bps > 1 else dt(1.0)
     marks = np.arange(-(levels - 1) - 6, levels + 6, dtype=np.float64)             # levels, boundaries, beyond the edge
     # ... and the margins around the boundaries inside which the threshold decision defers to the scan
-    marks = np.concatenate([marks] + [marks + o for o in (2.0 ** -12, -2.0 ** -12, 2.0 ** -10, -2.0 ** -10, 2.0 ** -13, -2.0 ** -13, 28.0, -28.0, 28.5, -28.5)])
+    # (round 3: the slicer's reach test |re| + |im| <= (L - 1) + 62 grid units replaced the per-axis one at 28 beyond the edge)
+    marks = np.concatenate([marks] + [marks + o for o in (2.0 ** -12, -2.0 ** -12, 2.0 ** -10, -2.0 ** -10, 2.0 ** -13, -2.0 ** -13, 28.0, -28.0, 28.5, -28.5,
+                                                             56.0, -56.0, 62.0, -62.0, 62.5, -62.5)])
     near = []
     for v in marks:
         x = dt(v) / inorm
@@ -220,6 +222,9 @@ def test_nearest_adversarial_points_bit_exact(ctx, oracle, bps, dt):
     near = np.array(near, dtype=dt)
     other = np.array([0.0, 1e-30, -1e-30, 0.37, -0.91, 1.0, 3.0, 40.0, -2.5e3, 1e6, -1e9, 3e18, np.inf, -np.inf, np.nan], dtype=dt)
     other = np.concatenate([other, (np.arange(-(levels - 1), levels, 2, dtype=np.float64) / float(inorm)).astype(dt)])
+    # partners far out but still inside (or just outside) the reach of the slicer: their squares are where one ulp of the sum is largest
+    far = np.array([levels - 1 + o for o in (20.0, 45.0, 55.0, 60.0, 61.0, 61.9, 62.0, 62.1, 64.0)])
+    other = np.concatenate([other, (far / float(inorm)).astype(dt), (-far / float(inorm)).astype(dt)])
     a, b = np.meshgrid(near, other, indexing="ij")
     cdt = np.complex64 if dt is np.float32 else np.complex128
     pts = np.empty(2 * a.size, dtype=cdt)                       # assembled by parts: 1j * inf would make NaNs
