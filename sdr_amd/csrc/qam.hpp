@@ -194,46 +194,49 @@ __device__ inline unsigned nearest_fast(T ur, T ui)
     return nearest_by_scan<T, MI, MQ>(ur, ui);
 }
 
-// One axis of the margin slicer, on the HALF coordinate s = v / 2 (v = point * inorm, the scan's coordinate; the
-// halving is exact, so s may be formed as re * (inorm / 2) in one product): binary level index and the distance of the
-// slicer coordinate t = s + (L - 1) / 2 from the centre of its decision cell (slicer units: one unit = two grid
-// units).  fl(s + (L - 1) / 2) is the value the two-step form fl(fl(v + (L - 1)) * 0.5) had.
+__device__ __forceinline__ float fused_mul_add(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fused_mul_add(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+// One axis of the margin slicer: binary level index (as a float) and the distance of the slicer coordinate
+//   t = fl(x * scale + (L - 1) / 2)        (one fused operation; slicer units: one unit = two grid units)
+// from the centre of its decision cell.  (x, scale) is (re, inorm / 2) or (v, 1/2) with v = fl(re * inorm) the scan's
+// own coordinate: x * scale is v / 2 up to the rounding of v, so t is within 2^-18 of v / 2 + (L - 1) / 2 while |t| < 64.
 template <typename T, int M>
-__device__ inline void axis_slice(T s, T& level, T& miss)
+__device__ __forceinline__ void axis_slice(T x, T scale, T& level, T& miss)
 {
     if constexpr (M == 0) {
         level = T(0);
         miss = T(0);
     } else {
         constexpr int L = 1 << M;
-        const T t = s + T(L - 1) * T(0.5);
-        T tc = t > T(-0.25) ? t : T(-0.25);                       // NaN -> -0.25 (the reach test below sees the NaN)
+        const T t = fused_mul_add(x, scale, T(L - 1) * T(0.5));
+        T tc = t > T(-0.25) ? t : T(-0.25);                       // NaN -> -0.25 (the reach test sees the NaN)
         tc = tc < T(L) - T(0.75) ? tc : T(L) - T(0.75);
         level = rint(tc);                                         // 0 ... L-1
         miss = tc - level;
     }
 }
-
 #ifndef SDR_MARGIN_OFF
 #define SDR_MARGIN_OFF 0     // 1: experiment, every hard decision takes the three-point test
 #endif
 
-// nearest() from a plain slicer whenever the point is CLEARLY inside one decision cell, about a third
+// nearest() from a plain slicer whenever the point is CLEARLY inside one decision cell, about a quarter
 // of the instructions of the three-point test.  (A, B) is accepted when, on both axes, the slicer
 // coordinate t is at most 1/2 - 2^-14 from the cell centre (the outer cells extend outwards) and the point's
-// reach |s_I| + |s_Q| is at most (L - 1) / 2 + 31 (a NaN on either axis fails this test: the sum, unlike a maximum,
-// does not lose it).  Why this is the scan's answer, float or double:
-//   * |t| <= |s| + (L - 1) / 2 < 64, so t carries an error below 2^-19 and v is at most 1 - 2^-13 + 2^-18 from level
-//     A and at least 1 + 2^-13 - 2^-18 from every other level of that axis; beyond the grid the
+// reach (|v_I| + |v_Q|) / 2 is at most R = (L - 1) / 2 + 31, tested as |x_I| + |x_Q| <= (R / scale) (1 - 2^-20) on the
+// unscaled coordinates (a NaN on either axis fails this test: the sum, unlike a maximum, does not lose it).  Why this
+// is the scan's answer, float or double:
+//   * |t| <= R + (L - 1) / 2 < 64, so t is within 2^-18 of the slicer coordinate of v and v is at most 1 - 2^-13 + 2^-17
+//     from level A and at least 1 + 2^-13 - 2^-17 from every other level of that axis; beyond the grid the
 //     nearest other level is 2 further than the edge level;
 //   * the scan's rounded axis distances are monotonic in |v - level|, so every other level's squared distance
-//     exceeds A's by at least that of the neighbour: 4 (1 - 2^-5) 2^-13 > 1.9 * 2^-12 inside, more than 4 outside;
+//     exceeds A's by at least that of the neighbour: 4 (1 - 2^-4) 2^-13 > 1.8 * 2^-12 inside, more than 4 outside;
 //   * the reach bound leaves a coordinate at most 30.5 slicer units beyond the outer cell of its axis (and the two
 //     excesses together no more): the distance to the own cell's level is at most 62 grid units on one axis with at
 //     most 1 + 2^-13 on the other (the sum of squares is convex, so the split excess is smaller), i.e. every sum m is
-//     below 2^12, where one ulp is at most 2^-12: a point that differs from (A, B) on either axis has an exact sum at
-//     least 1.9 ulp larger and therefore a strictly larger rounded one.  m is finite, so the strict '<' scan returns
-//     (A, B).
+//     below 2^12, where one ulp is at most 2^-12: a point that differs from (A, B) on either axis has an exact sum
+//     more than 1.8 ulp larger and therefore a strictly larger rounded one.  m is finite, so the strict '<' scan
+//     returns (A, B).
 // Everything else -- one point in 4000 of a uniform spread, NaN, far outliers -- takes the
 // three-point test (and from there, rarely, the scan).
 template <typename T, int MI, int MQ>
@@ -242,22 +245,22 @@ __device__ __noinline__ unsigned nearest_checked(T ur, T ui) { return nearest_fa
 template <typename T, int MI, int MQ>
 struct MarginSlicer {
     static constexpr int LMAX = 1 << (MI > MQ ? MI : MQ);
-    static __device__ __forceinline__ T reach_limit() { return T(LMAX - 1) * T(0.5) + T(31); }
+    // limit of |x_I| + |x_Q| for coordinates that still have to be multiplied by `scale` to become half coordinates
+    static __device__ __forceinline__ T reach_limit(T scale) { return (T(LMAX - 1) * T(0.5) + T(31)) / scale * (T(1) - T(1.0 / 1048576.0)); }
     static __device__ __forceinline__ T miss_limit() { return T(0.5) - T(0.00006103515625); }
-    // slicer proposal for the half coordinates (si, sq): both binary level indices as one word (I above Q, not yet
-    // Gray-coded), the larger distance from a cell centre and the reach
-    static __device__ __forceinline__ unsigned propose(T si, T sq, T& miss, T& reach)
+    // slicer proposal: both binary level indices as one number level_I * 2^MQ + level_Q (exact in T, not yet
+    // Gray-coded), the larger distance from a cell centre (never NaN: the clamp) and the reach (NaN if either is)
+    static __device__ __forceinline__ T propose(T xi, T xq, T scale, T& miss, T& reach)
     {
         T ai, aq, mi, mq;
-        axis_slice<T, MI>(si, ai, mi);
-        axis_slice<T, MQ>(sq, aq, mq);
-        miss = fmax(fabs(mi), fabs(mq));                           // never NaN (the clamp)
-        reach = fabs(si) + fabs(sq);                               // NaN if either is
-        const unsigned bi = static_cast<unsigned>(static_cast<int>(ai));
-        if constexpr (MQ == 0) return bi;
-        else return (bi << MQ) | static_cast<unsigned>(static_cast<int>(aq));
+        axis_slice<T, MI>(xi, scale, ai, mi);
+        axis_slice<T, MQ>(xq, scale, aq, mq);
+        miss = fmax(fabs(mi), fabs(mq));
+        reach = fabs(xi) + fabs(xq);
+        if constexpr (MQ == 0) return ai;
+        else return fused_mul_add(ai, T(1 << MQ), aq);
     }
-    static __device__ __forceinline__ bool sure(T miss, T reach) { return (miss <= miss_limit()) && (reach <= reach_limit()); }
+    static __device__ __forceinline__ bool sure(T miss, T reach, T limit) { return static_cast<bool>(static_cast<int>(miss <= miss_limit()) & static_cast<int>(reach <= limit)); }      // no short circuit: two compares and a scalar AND
     // Gray-codes both axes of the proposal in one go
     static __device__ __forceinline__ unsigned gray(unsigned w)
     {
@@ -266,15 +269,15 @@ struct MarginSlicer {
     }
 };
 
-// (si, sq) = half coordinates (exactly (ur, ui) / 2); (ur, ui) only feed the out-of-line test
+// (xi, xq) * scale = half coordinates (exactly or to the last bit (ur, ui) / 2); (ur, ui) only feed the out-of-line test
 template <typename T, int MI, int MQ>
-__device__ inline unsigned nearest_margin(T si, T sq, T ur, T ui)
+__device__ inline unsigned nearest_margin(T ur, T ui)
 {
     if constexpr (SDR_MARGIN_OFF) return nearest_fast<T, MI, MQ>(ur, ui);
     using MS = MarginSlicer<T, MI, MQ>;
     T miss, reach;
-    const unsigned w = MS::propose(si, sq, miss, reach);
-    if (MS::sure(miss, reach)) return MS::gray(w);
+    const T w = MS::propose(ur, ui, T(0.5), miss, reach);
+    if (MS::sure(miss, reach, MS::reach_limit(T(0.5)))) return MS::gray(static_cast<unsigned>(static_cast<int>(w)));
     return nearest_checked<T, MI, MQ>(ur, ui);
 }
 
@@ -283,16 +286,16 @@ template <typename T, int MI, int MQ, bool WANT_LLR, bool WANT_IDX>
 __device__ inline unsigned demap_point(T re, T im, T inorm, T w, T* llr)
 {
     if constexpr (!WANT_LLR) {
-        // hard decision alone: no need for every distance (4-level axes gain nothing from it); the half coordinates
-        // come from one product each (re * (inorm / 2) is exactly (re * inorm) / 2), the scan's own coordinates are
-        // formed only where the out-of-line test wants them
+        // hard decision alone: no need for every distance (4-level axes gain nothing from it); the slicer works on the
+        // unscaled point (one fused operation per axis), the scan's own coordinates are formed only where the
+        // out-of-line test wants them
         if constexpr (WANT_IDX && (MI >= SDR_FAST_FROM || MQ >= SDR_FAST_FROM)) {
             if constexpr (SDR_MARGIN_OFF) return nearest_fast<T, MI, MQ>(re * inorm, im * inorm);
             using MS = MarginSlicer<T, MI, MQ>;
             const T half = inorm * T(0.5);
             T miss, reach;
-            const unsigned w2 = MS::propose(re * half, im * half, miss, reach);
-            if (MS::sure(miss, reach)) return MS::gray(w2);
+            const T w2 = MS::propose(re, im, half, miss, reach);
+            if (MS::sure(miss, reach, MS::reach_limit(half))) return MS::gray(static_cast<unsigned>(static_cast<int>(w2)));
             return nearest_checked<T, MI, MQ>(re * inorm, im * inorm);
         }
     }
@@ -309,7 +312,7 @@ __device__ inline unsigned demap_point(T re, T im, T inorm, T w, T* llr)
     unsigned idx = 0;
     if constexpr (WANT_IDX) {
         // even with every distance at hand the three-point test is cheaper than the scan from 8 levels up
-        if constexpr (MI >= SDR_FAST_FROM || MQ >= SDR_FAST_FROM) idx = nearest_margin<T, MI, MQ>(ur * T(0.5), ui * T(0.5), ur, ui);
+        if constexpr (MI >= SDR_FAST_FROM || MQ >= SDR_FAST_FROM) idx = nearest_margin<T, MI, MQ>(ur, ui);
         else idx = nearest_from_distances<T, MI, MQ>(dx, dy);
     }
     return idx;

@@ -500,6 +500,7 @@ struct RxShape {
     static constexpr int IDX_OFF = IDX_ALIAS ? (STG_ALIAS ? (STG_BYTES + 15) & ~15 : 0) : DATA_BYTES + TW_BYTES;
     static constexpr int REF_OFF = REF_ALIAS ? (IDX_OFF + IDX_RAW_BYTES + 15) & ~15 : DATA_BYTES + TW_BYTES + IDX_BYTES;
     static_assert(!IDX_ALIAS || IDX_OFF + IDX_RAW_BYTES <= DATA_BYTES, "aliased hard decisions fit the exchange region");
+    static_assert(IDX_OFF % 16 == 0, "the packing step reads the decisions sixteen at a time");
     static_assert(!REF_ALIAS || REF_OFF + REF_RAW_BYTES <= DATA_BYTES, "aliased reference bits fit the exchange region");
     static constexpr int STG_OFF = STG_ALIAS ? 0 : (DATA_BYTES + TW_BYTES + IDX_BYTES + REF_BYTES + 15) & ~15;
     static constexpr int LDS_USED = (STG_ALIAS ? DATA_BYTES + TW_BYTES + IDX_BYTES + REF_BYTES : STG_OFF + STG_BYTES) + 16;
@@ -878,6 +879,42 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
         [[maybe_unused]] auto pack_hard = [&]() {
             if constexpr (HARD_PATH) if (HARDONLY || p.hard) {
                 __syncthreads();
+                if constexpr (sizeof(idx_t) == 1 && BPS % 2 == 0 && N % 16 == 0) {
+                    // A thread takes 16 consecutive decisions with one 16-byte LDS read, squeezes their 16 * BPS bits into
+                    // BPS / 2 words of the MSB-first stream in registers and stores them with one instruction (a wave writes
+                    // 64 * 2 * BPS contiguous bytes).  The word-by-word form it replaces read every decision as a single
+                    // byte (7 LDS reads and ~28 instructions per word at 64-QAM).
+                    constexpr int NW = BPS / 2;                                   // words per 16 decisions
+                    constexpr int CHUNKS = N / 16;
+                    if (active) {
+                        for (int c = t; c < CHUNKS; c += TPS) {
+                            const uint4 r4 = *reinterpret_cast<const uint4*>(lds_idx + slot * N + 16 * c);
+                            const uint32_t r[4] = {r4.x, r4.y, r4.z, r4.w};
+                            uint32_t q[4];                                         // 4 decisions = 4 * BPS bits, first decision highest
+                            static_for<4>([&](auto J) {
+                                constexpr int j = J;
+                                q[j] = ((r[j] & 0xffu) << (3 * BPS)) | (((r[j] >> 8) & 0xffu) << (2 * BPS)) | (((r[j] >> 16) & 0xffu) << BPS) | (r[j] >> 24);
+                            });
+                            uint32_t wds[NW];
+                            static_for<NW>([&](auto M_) {
+                                constexpr int m = M_;
+                                uint32_t acc = 0;
+                                static_for<4>([&](auto J) {
+                                    constexpr int j = J;
+                                    constexpr int sh = 32 * (m + 1) - 4 * BPS * (j + 1);       // position of q[j]'s lowest bit in word m
+                                    if constexpr (sh >= 0 && sh < 32) acc |= q[j] << sh;
+                                    else if constexpr (sh < 0 && sh > -4 * BPS) acc |= q[j] >> (-sh);
+                                });
+                                wds[m] = __builtin_bswap32(acc);
+                            });
+                            uint32_t* out = reinterpret_cast<uint32_t*>(p.hard + bin0 * BPS / 8) + NW * c;
+                            if constexpr (NW == 1) out[0] = wds[0];
+                            else if constexpr (NW == 2) { typedef uint32_t u2 __attribute__((ext_vector_type(2), aligned(4))); u2 v2 = {wds[0], wds[1]}; *reinterpret_cast<u2*>(out) = v2; }
+                            else if constexpr (NW == 3) { typedef uint32_t u3 __attribute__((ext_vector_type(3), aligned(4))); u3 v3 = {wds[0], wds[1], wds[2]}; *reinterpret_cast<u3*>(out) = v3; }
+                            else { typedef uint32_t u4 __attribute__((ext_vector_type(4), aligned(4))); u4 v4 = {wds[0], wds[1], wds[2], wds[3]}; *reinterpret_cast<u4*>(out) = v4; }
+                        }
+                    }
+                } else {
                 constexpr int WORDS = N * BPS / 32;
                 constexpr int CNT = (32 + BPS - 1) / BPS + 1;
                 if (active) {
@@ -895,6 +932,7 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
                         out[j] = __builtin_bswap32(word);
                     }
                 }
+                }
             }
         };
         // Hard decisions alone from 16-QAM up: the margin slicer (qam.hpp) runs over ALL of the thread's bins as one
@@ -908,36 +946,37 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
             using MS = MarginSlicer<float, MI, MQ>;
             constexpr int NG = E / GO;
             const float half = p.inorm * 0.5f;
-            unsigned long long doubt[NG];
-            unsigned long long any = 0;
+            const float limit = MS::reach_limit(half);
+            bool doubt[NG];      // per lane; the compiler keeps each as a scalar pair (the compares' own results)
+            bool any = false;
             static_for<NG>([&](auto Hh) {
                 constexpr int h = Hh;
                 const int k = O::reg_pos(LAST, h * GO) | pos_last;
                 bool ok = true;
-                unsigned w[GO];
+                float w[GO];      // level_I * 2^MQ + level_Q, an exact small integer
                 static_for<GO>([&](auto G) {
                     constexpr int g = G;
                     float miss, reach;
-                    w[g] = MS::propose(x[h * GO + g].x * half, x[h * GO + g].y * half, miss, reach);
-                    ok = ok && MS::sure(miss, reach);
+                    w[g] = MS::propose(x[h * GO + g].x, x[h * GO + g].y, half, miss, reach);
+                    ok = static_cast<bool>(static_cast<int>(ok) & static_cast<int>(MS::sure(miss, reach, limit)));
                 });
                 if constexpr (GO == 2 && sizeof(idx_t) == 1) {
-                    // both points Gray-coded in one go: the bytes keep their order in LDS (little endian: bin k first)
+                    // both points combined (exactly, in float) and Gray-coded in one go: the bytes keep their order in LDS
+                    // (little endian: bin k first)
                     constexpr unsigned keep1 = 0x7fu & (MQ > 0 ? ~(1u << (MQ - 1)) : ~0u);
-                    const unsigned pair = w[0] | (w[1] << 8);
+                    const unsigned pair = static_cast<unsigned>(static_cast<int>(__builtin_fmaf(w[1], 256.0f, w[0])));
                     const unsigned coded = pair ^ ((pair >> 1) & (keep1 | (keep1 << 8)));
                     *reinterpret_cast<uint16_t*>(lds_idx + slot * N + k) = static_cast<uint16_t>(coded);
                 } else {
-                    static_for<GO>([&](auto G) { constexpr int g = G; lds_idx[slot * N + k + g] = static_cast<idx_t>(MS::gray(w[g])); });
+                    static_for<GO>([&](auto G) { constexpr int g = G; lds_idx[slot * N + k + g] = static_cast<idx_t>(MS::gray(static_cast<unsigned>(static_cast<int>(w[g])))); });
                 }
-                doubt[h] = __ballot(!ok);
-                any |= doubt[h];
+                doubt[h] = !ok;
+                any = static_cast<bool>(static_cast<int>(any) | static_cast<int>(doubt[h]));
             });
-            if (any) {                                                  // uniform over the wave
-                const unsigned long long me = 1ull << (tid & 63);
+            if (__builtin_amdgcn_ballot_w64(any) != 0) {                // uniform over the wave
                 static_for<NG>([&](auto Hh) {
                     constexpr int h = Hh;
-                    if (doubt[h] & me) {
+                    if (doubt[h]) {
                         const int k = O::reg_pos(LAST, h * GO) | pos_last;
                         static_for<GO>([&](auto G) {
                             constexpr int g = G;
