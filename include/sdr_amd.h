@@ -133,7 +133,7 @@ int sdr_constellation_f32(int mod, float* norm, float* inorm, float* table);
  * the tap loads of the two-array form.  If d_ref_hard (same layout as d_hard) and d_counters are given, the
  * kernel also accumulates into d_counters[0..7] (uint64):
  *   [0] bit errors  [1] bits  [2] subcarrier-symbol errors  [3] subcarrier symbols
- *   [4] OFDM symbols  [5] sum trunc(min(|LLR|*1024, 2^30))  [6] LLR sign errors  [7] reserved.
+ *   [4] OFDM symbols  [5] sum round(min(|LLR|,64)/64*65535)  [6] LLR sign errors  [7] reserved.
  * Which outputs are asked for selects the kernel instantiation: d_llr alone is the fastest
  * (HBM bound); d_hard alone is the reference's own chain ofdm::rx -> from_constl in one launch;
  * any other combination runs the all-outputs instantiation.  n_fft 64..8192 with even cp and

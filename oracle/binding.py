@@ -242,3 +242,12 @@ def count_bit_errors(a, b):
     b = _c(b, np.uint8).ravel()
     assert a.size == b.size
     return int(lib().orc_count_bit_errors(_p(a), _p(b), c_size_t(a.size)))
+
+
+def llr_abs_units(llr):
+    """Counter 5 per LLR: round(min(|L|, 64) / 64 * 65535), NaN -> 0 (numpy restatement of llr_stats in sdr_oracle.cpp;
+    the product is exact in float64 and never lies on a tie)."""
+    x = np.abs(np.asarray(llr, dtype=np.float32)) * np.float32(0.015625)
+    x = np.where(np.isnan(x), np.float32(0.0), np.minimum(x, np.float32(1.0)))
+    return np.floor(x.astype(np.float64) * 65535.0 + 0.5).astype(np.int64)
+

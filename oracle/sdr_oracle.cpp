@@ -513,14 +513,14 @@ void demod_symbol(const Constellation& c, std::uint32_t n_fft, std::uint32_t cp,
 inline std::uint64_t popcount32(std::uint32_t v) { return static_cast<std::uint64_t>(__builtin_popcount(v)); }
 
 // LLR statistics kept as integers so that sums do not depend on reduction order:
-//   q = trunc(min(|L|*1024, 2^30)), and a sign error is (L < 0) != transmitted bit.
+//   q = round(min(|L|, 64) / 64 * 65535) (|L| clipped at 64, steps of 64/65535; NaN counts 0; the product is exact in
+//   double and never lies on a tie), and a sign error is (L < 0) != transmitted bit.
 inline void llr_stats(const float* llr, int bps, unsigned tx_idx, std::uint64_t& abs_q10, std::uint64_t& sign_err)
 {
     for (int b = 0; b < bps; ++b) {
         const float l = llr[b];
-        float a = std::fabs(l) * 1024.0f;
-        if (!(a < 1073741824.0f)) a = 1073741824.0f;     // also catches NaN
-        abs_q10 += static_cast<std::uint64_t>(static_cast<std::int64_t>(a));
+        const float x = std::fabs(l) * 0.015625f;        // exact (a power of two)
+        if (x == x) abs_q10 += static_cast<std::uint64_t>(std::floor(static_cast<double>(x < 1.0f ? x : 1.0f) * 65535.0 + 0.5));
         const unsigned txbit = (tx_idx >> (bps - 1 - b)) & 1u;
         const unsigned rxbit = (l < 0.0f) ? 1u : 0u;
         sign_err += (txbit != rxbit);
@@ -783,7 +783,7 @@ int orc_link_generate_c32(std::uint32_t n_fft, std::uint32_t cp, int bps, std::u
 
 // Monte-Carlo link (X4): generate -> demodulate -> count, nothing stored.
 // counters[0] bit errors, [1] bits, [2] subcarrier-symbol errors, [3] subcarrier symbols,
-// [4] OFDM symbols, [5] sum of trunc(min(|LLR|*1024, 2^30)), [6] LLR sign errors, [7] reserved.
+// [4] OFDM symbols, [5] sum of round(min(|LLR|, 64) / 64 * 65535), [6] LLR sign errors, [7] reserved.
 int orc_link_ber_c32(std::uint32_t n_fft, std::uint32_t cp, int bps, std::uint64_t seed, std::uint64_t g0, std::size_t n_sym,
                      float sigma, float w0, std::uint64_t* counters /* 8, accumulated into */)
 {

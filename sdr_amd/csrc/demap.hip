@@ -345,11 +345,9 @@ __global__ void demap_fft_kernel(const float2* __restrict__ fft, uint32_t n_fft,
             bit_err += __popc(diff);
             sym_err += (diff != 0);
             n_done += 1;
+            abs_q += llr_abs_sum<BPS>(l, 0u);
 #pragma unroll
             for (int b = 0; b < BPS; ++b) {
-                float a = fabsf(l[b]) * 1024.0f;
-                a = (a < 1073741824.0f) ? a : 1073741824.0f;
-                abs_q += static_cast<unsigned long long>(static_cast<long long>(a));
                 const unsigned txbit = (ref >> (BPS - 1 - b)) & 1u;
                 sign_err += (txbit != (l[b] < 0.0f ? 1u : 0u));
             }

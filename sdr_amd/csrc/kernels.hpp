@@ -44,7 +44,8 @@ int rx_set_tuning(const char* name, long value);
 int copy_shape_launch(sdr_ctx* ctx, const void* d_rx, uint32_t n_fft, uint32_t cp, uint32_t bps, uint64_t n_sym, float* d_out);
 
 // link.hip: frame generator, AWGN, Monte-Carlo link.
-int link_generate(sdr_ctx* ctx, const sdr_link_args& a);
+// skip_prefix: the cyclic prefix of every symbol is left unwritten (for a consumer that drops it: the chain's receive kernel)
+int link_generate(sdr_ctx* ctx, const sdr_link_args& a, bool skip_prefix = false);
 int link_ber(sdr_ctx* ctx, const sdr_link_args& a);
 int link_sweep(sdr_ctx* ctx, const sdr_sweep_args& a);
 int link_channel(sdr_ctx* ctx, uint32_t n_fft, uint64_t seed, uint64_t first_set, size_t n_sets, void* d_chan);

@@ -175,7 +175,7 @@ int check_link(const sdr_link_args& a)
 
 } // namespace
 
-int link_generate(sdr_ctx* ctx, const sdr_link_args& a)
+int link_generate(sdr_ctx* ctx, const sdr_link_args& a, bool skip_prefix)
 {
     SDR_TRY(check_link(a));
     if (a.n_sym == 0) return SDR_OK;
@@ -194,6 +194,7 @@ int link_generate(sdr_ctx* ctx, const sdr_link_args& a)
         p.n_sym = a.n_sym; p.seed = a.seed; p.first_symbol = a.first_symbol;
         p.cp = a.cp; p.sym_per_set = a.sym_per_set; p.sigma = a.sigma;
         p.norm = 1.0f / std::sqrt(static_cast<float>(grid_energy(static_cast<int>(a.mod))));
+        p.skip_prefix = skip_prefix ? 1u : 0u;      // (the generic path below always writes the prefix)
         return tx_dispatch(ctx, ilog2(a.n_fft), p, static_cast<int>(a.mod));
     }
     const size_t total = size_t(a.n_sym) * a.n_fft;
@@ -528,7 +529,8 @@ int link_chain(sdr_ctx* ctx, const sdr_chain_args& a)
         g.n_fft = a.n_fft; g.cp = a.cp; g.mod = a.mod; g.seed = a.seed;
         g.first_symbol = a.first_symbol + done; g.n_sym = now; g.sym_per_set = a.sym_per_set; g.sigma = a.sigma;
         g.d_chan = ws + l.chan[b]; g.d_rx = ws + l.rx[b]; g.d_tx_bits = ws + l.bits[b];
-        SDR_TRY(link_generate(ctx, g));
+        // the receive kernel drops the prefix on load (lib/inc/ofdm.hpp:41): the chain's generator neither draws its noise nor stores it
+        SDR_TRY(link_generate(ctx, g, true));
         SDR_HIP(hipEventRecord(ctx->chain_generated[b], gen_stream));
         return SDR_OK;
     };

@@ -35,6 +35,7 @@ struct TxParams {
     float sigma;                 // 0 with NOISE = false
     float norm;
     uint32_t groups_per_wg;
+    uint32_t skip_prefix;        // generator: the cyclic prefix is neither computed nor stored (a receiver never reads it, lib/inc/ofdm.hpp:41)
 };
 
 struct McParams {
@@ -285,7 +286,7 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
         __syncthreads();
         // cyclic prefix first (ofdm.hpp:21 copies the clean tail; its noise is a stream of its own,
         // samples c and c + ceil(cp/2) sharing one Philox block)
-        if (active) {
+        if (active && !p.skip_prefix) {
             if constexpr (NOISE) {
                 const int half = static_cast<int>(cp_half(p.cp));
 #pragma unroll 1
@@ -334,22 +335,7 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
         if constexpr (!SRC_GLOBAL) {
             if (p.tx_bits) {
                 __syncthreads();
-                constexpr int WORDS = N * BPS / 32;
-                constexpr int CNT = (32 + BPS - 1) / BPS + 1;
-                if (active) {
-                    uint32_t* out = reinterpret_cast<uint32_t*>(p.tx_bits + static_cast<size_t>(sym) * N * BPS / 8);
-                    for (int j = t; j < WORDS; j += TPS) {
-                        const int k0 = (32 * j) / BPS;
-                        const int off = 32 * j - k0 * BPS;
-                        unsigned long long acc = 0;
-#pragma unroll
-                        for (int i = 0; i < CNT; ++i) {
-                            const int kk = (k0 + i < N) ? k0 + i : N - 1;
-                            acc = (acc << BPS) | lds_idx[slot * N + kk];
-                        }
-                        out[j] = __builtin_bswap32(static_cast<uint32_t>(acc >> (CNT * BPS - off - 32)));
-                    }
-                }
+                if (active) pack_decisions<N, BPS, idx_t>(lds_idx + slot * N, p.tx_bits + static_cast<size_t>(sym) * N * BPS / 8, t, TPS);
             }
         }
         if constexpr (LOOP) __syncthreads();
@@ -418,7 +404,6 @@ __device__ __forceinline__ void mc_body(const McWork& p, unsigned char* lds, con
         if (!active) sym = p.n_sym - 1;
         const unsigned long long g = p.first_symbol + sym;
 
-        const unsigned long long abs_before = c_abs;
         // ---- transmit: indices -> constellation -> IFFT -> /N -> + noise ----
         float2 x[E];
         for_each_tx_index<LOG2N, BPS, false>(p.seed, g, addr.in_thread, [&](auto M, uint32_t idx) {
@@ -463,7 +448,7 @@ __device__ __forceinline__ void mc_body(const McWork& p, unsigned char* lds, con
         if constexpr (ALIAS_SYNC) __syncthreads();
         static_for<E>([&](auto M) { constexpr int m = M; lds_time[slot * N + (A::out_reg(m) | addr.pos_last)] = x[m]; });
         __syncthreads();
-        unsigned n_bit = 0, n_sym_err = 0, n_sign = 0;              // per symbol and thread: <= 16 points x 10 bits
+        unsigned n_bit = 0, n_sym_err = 0, n_sign = 0, n_abs = 0;   // per symbol and thread: <= 16 points x 10 bits (x 65535 for n_abs)
 #pragma unroll 1
         for (int j = 0; j < E / 8; ++j) {
             const int block = j * TPS + t;
@@ -480,21 +465,13 @@ __device__ __forceinline__ void mc_body(const McWork& p, unsigned char* lds, con
                 n_bit += __popc(diff);
                 n_sym_err += (diff != 0);
                 if constexpr (HARD) continue;
-                unsigned two = 0, negative = 0;
-                static_for<BPS>([&](auto B) {
-                    constexpr int b = B;
-                    const float a = fminf(fabsf(l[b]) * 1024.0f, 1073741824.0f);      // NaN -> 2^30, like the compare it replaces
-                    // a in [0, 2^30]: the 32-bit truncation is the 64-bit one; two of them fit 32 bits
-                    if constexpr (b % 2 == 0) two = static_cast<unsigned>(static_cast<int>(a));
-                    else { c_abs += two + static_cast<unsigned>(static_cast<int>(a)); two = 0; }
-                    negative = (negative << 1) | (l[b] < 0.0f ? 1u : 0u);
-                });
+                unsigned negative = 0;
+                static_for<BPS>([&](auto B) { constexpr int b = B; negative = (negative << 1) | (l[b] < 0.0f ? 1u : 0u); });
                 n_sign += __popc(negative ^ ref);
-                c_abs += two;
+                n_abs = llr_abs_sum<BPS>(l, n_abs);                 // counter 5 (qam.hpp); E * 10 * 65535 per symbol fits 32 bits
             }
         }
-        if (active) { c_bit += n_bit; c_sym += n_sym_err; c_sign += n_sign; c_n += E; }
-        else c_abs = abs_before;
+        if (active) { c_bit += n_bit; c_sym += n_sym_err; c_sign += n_sign; c_abs += n_abs; c_n += E; }
         __syncthreads();
     }
 

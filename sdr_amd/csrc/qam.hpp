@@ -281,6 +281,30 @@ __device__ inline unsigned nearest_margin(T ur, T ui)
     return nearest_checked<T, MI, MQ>(ur, ui);
 }
 
+// LLR magnitude statistic (counter 5, no reference counterpart): every LLR adds
+//   q(L) = round(min(|L|, 64) / 64 * 65535)        (NaN adds 0; a tie cannot occur: x * 65535 is never k + 1/2)
+// i.e. |L| clipped at 64 in steps of 64/65535 = 0.977e-3 -- an integer, so that sums do not depend on the order
+// of reduction.  This is what v_cvt_pknorm_u16_f32 computes for two values at once (checked against the formula over
+// every float in [0, 1] on MI355X: tools/pknormcheck.hip), and v_dot2_u32_u16 adds both halves to a 32-bit sum:
+// two instructions per pair of LLRs plus the exact scaling by 2^-6, where trunc(min(|L| * 1024, 2^30)) of rounds 1-2
+// cost four per LLR.  `acc` must have room for 2 * 65535 more.
+typedef unsigned short sdr_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned llr_abs_add2(float l0, float l1, unsigned acc)
+{
+    const sdr_u16x2 q = __builtin_amdgcn_cvt_pknorm_u16(__builtin_fabsf(l0 * 0.015625f), __builtin_fabsf(l1 * 0.015625f));
+    const sdr_u16x2 ones = {1, 1};
+    return __builtin_amdgcn_udot2(q, ones, acc, false);
+}
+// sum over `COUNT` LLRs held in an array
+template <int COUNT>
+__device__ __forceinline__ unsigned llr_abs_sum(const float* l, unsigned acc)
+{
+#pragma unroll
+    for (int i = 0; i + 1 < COUNT; i += 2) acc = llr_abs_add2(l[i], l[i + 1], acc);
+    if constexpr (COUNT % 2 == 1) acc = llr_abs_add2(l[COUNT - 1], 0.0f, acc);
+    return acc;
+}
+
 // Everything for one subcarrier: scaled coordinates -> LLRs (MI+MQ values) and index.
 template <typename T, int MI, int MQ, bool WANT_LLR, bool WANT_IDX>
 __device__ inline unsigned demap_point(T re, T im, T inorm, T w, T* llr)

@@ -94,6 +94,25 @@ __device__ inline void sincos_turn(uint32_t k24, float& s, float& c, Tab tab)
     c = a.y * cb - a.x * sb;
 }
 
+// Correctly rounded square root of t in [0, 2^6] (never subnormal unless 0): the hardware's 1-ulp estimate, moved to a
+// neighbour when the residual says so -- the compiler's own sqrtf minus its scaling of tiny arguments and its
+// zero / infinity patch (about half the instructions).  The result is the IEEE square root, i.e. what sqrtf returns on the CPU.
+__device__ inline float sqrt_rn_small(float t)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float y = __builtin_amdgcn_sqrtf(t);
+    const float down = __uint_as_float(__float_as_uint(y) - 1u);      // t = 0: NaN, never taken
+    const float up = __uint_as_float(__float_as_uint(y) + 1u);
+    const float r_down = __builtin_fmaf(-down, y, t);
+    const float r_up = __builtin_fmaf(-up, y, t);
+    float r = (r_down <= 0.0f) ? down : y;
+    r = (r_up > 0.0f) ? up : r;
+    return r;
+#else
+    return sqrtf(t);
+#endif
+}
+
 // Box-Muller on a 32-bit uniform u1 in [2^-32, 1] and a 24-bit angle: |z| <= sqrt(64 ln 2) sigma = 6.66 sigma
 template <typename Tab>
 __device__ inline float2 gaussian_pair(uint32_t x1, uint32_t x2, float sigma, Tab tab)
@@ -101,7 +120,7 @@ __device__ inline float2 gaussian_pair(uint32_t x1, uint32_t x2, float sigma, Ta
     const float u1 = (static_cast<float>(x1) + 1.0f) * 2.3283064365386963e-10f;
     float t = -2.0f * ln_unit(u1, tab);
     t = (t > 0.0f) ? t : 0.0f;                      // u1 = 1: the table form of ln may come out a few 1e-9 above 0
-    const float rad = sqrtf(t);                     // correctly rounded (hipcc default); __fsqrt_rn is the native 1-ulp form
+    const float rad = sqrt_rn_small(t);             // correctly rounded, t <= 64 ln 2
     float s, c;
     sincos_turn(x2 >> 8, s, c, tab);
     const float a = sigma * rad;

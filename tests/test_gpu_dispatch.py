@@ -76,7 +76,7 @@ def _run_case(ctx, oracle, n, cp, bps, n_sym, taps, shifts, seed):
     assert c[0] == oracle.count_bit_errors(ref["hard"], bits)
     assert c[1] == n_sym * n * bps and c[3] == n_sym * n and c[4] == n_sym
     l = ref["llr"].reshape(-1, bps)
-    q = np.minimum(np.abs(l) * np.float32(1024.0), np.float32(1073741824.0)).astype(np.int64)
+    q = oracle.llr_abs_units(l)
     tx = np.unpackbits(bits).reshape(-1, bps)
     assert c[2] == int((tx != np.unpackbits(ref["hard"]).reshape(-1, bps)).any(axis=1).sum())
     assert c[5] == int(q.sum())

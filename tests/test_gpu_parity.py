@@ -310,7 +310,7 @@ def test_demod_parity(ctx, oracle, n, cp, bps):
     rxb = np.unpackbits(ref["hard"]).reshape(-1, bps)
     assert c[2] == int((tx != rxb).any(axis=1).sum())
     l = ref["llr"].reshape(-1, bps)
-    q = np.minimum(np.abs(l) * np.float32(1024.0), np.float32(1073741824.0)).astype(np.int64)
+    q = oracle.llr_abs_units(l)
     assert c[5] == int(q.sum())
     assert c[6] == int(((l < 0).astype(np.uint8) != tx).sum())
     # a second call accumulates
@@ -393,7 +393,7 @@ def test_demod_random_configurations(ctx, oracle, i, n, cp, bps, n_sym, taps, ou
         assert c[0] == oracle.count_bit_errors(ref["hard"], bits)
         assert c[1] == n_sym * n * bps and c[3] == n_sym * n and c[4] == n_sym
         l = ref["llr"].reshape(-1, bps)
-        q = np.minimum(np.abs(l) * np.float32(1024.0), np.float32(1073741824.0)).astype(np.int64)
+        q = oracle.llr_abs_units(l)
         assert c[5] == int(q.sum())
         assert c[6] == int(((l < 0).astype(np.uint8) != np.unpackbits(bits).reshape(-1, bps)).sum())
 
@@ -471,7 +471,7 @@ def test_demod_weight_from_taps(ctx, oracle, n, cp, bps, per):
                      ref_hard=dev(bits), counters=cnt)
     assert same(full.llr.cpu().numpy(), ref["llr"]) and same(full.hard.cpu().numpy(), ref["hard"]) and same(full.fft.cpu().numpy(), ref["fft"])
     l = ref["llr"].reshape(-1, bps)
-    q = np.minimum(np.abs(l) * np.float32(1024.0), np.float32(1073741824.0)).astype(np.int64)
+    q = oracle.llr_abs_units(l)
     c = cnt.cpu().numpy()
     assert c[0] == oracle.count_bit_errors(ref["hard"], bits) and c[5] == int(q.sum())
     # taps alone WITHOUT the flag: the scalar weight (and no weight load either)
