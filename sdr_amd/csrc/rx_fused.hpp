@@ -393,30 +393,6 @@ __device__ __forceinline__ void stream_store2(float* dst, float a, float b)
 }
 
 
-// 16 / 8 bytes per lane through a buffer resource with an explicit cache policy (AUX: bit 0 = sc0, bit 1 = nt, bit 4 = sc1)
-typedef unsigned sdr_v4u __attribute__((ext_vector_type(4)));
-typedef unsigned sdr_v2u __attribute__((ext_vector_type(2)));
-template <int AUX>
-__device__ __forceinline__ float4 policy_load16(const void* base, unsigned bytes, unsigned off)
-{
-    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, static_cast<int>(bytes), 0x00020000);
-    const sdr_v4u v = __builtin_amdgcn_raw_buffer_load_b128(r, static_cast<int>(off), 0, AUX);
-    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-}
-template <int AUX>
-__device__ __forceinline__ float2 policy_load8(const void* base, unsigned bytes, unsigned off)
-{
-    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, static_cast<int>(bytes), 0x00020000);
-    const sdr_v2u v = __builtin_amdgcn_raw_buffer_load_b64(r, static_cast<int>(off), 0, AUX);
-    return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
-}
-#ifndef SDR_TAP_AUX
-#define SDR_TAP_AUX -1
-#endif
-#ifndef SDR_SAMPLE_AUX
-#define SDR_SAMPLE_AUX -1
-#endif
-
 // LLR staging through LDS: per-lane chunk of C floats -> lane-contiguous vectors (coalesced stores)
 constexpr int stage_stride_bytes(int c) { return c == 6 ? 24 : c == 8 ? 48 : c == 12 ? 48 : c == 16 ? 80 : c == 20 ? 80 : c * 4; }
 constexpr bool stage_wanted(int c) { return c == 6 || c == 8 || c == 10 || c == 12 || c == 16 || c == 20; }
@@ -746,9 +722,7 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
             } else {
                 // register bit kR[0] is the group bit: adjacent input samples
                 float4 v;
-                if constexpr (SDR_SAMPLE_AUX >= 0 && SPW == 1 && EQ) {
-                    v = policy_load16<SDR_SAMPLE_AUX>(p.rx + s_ * in_stride + p.cp, N * 8, static_cast<unsigned>(in_thread + idx0) * 8u);
-                } else if constexpr (S::NT_SAMPLES) {
+                if constexpr (S::NT_SAMPLES) {
                     const sdr_v4f q = __builtin_nontemporal_load(reinterpret_cast<const sdr_v4f*>(src + idx0));
                     v = make_float4(q.x, q.y, q.z, q.w);
                 } else {
@@ -812,15 +786,11 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
                 constexpr int h = Hh;
                 const int k = O::reg_pos(LAST, h * GO_) | pos_last;
                 if constexpr (GO_ == 2) {
-                    float4 v;
-                    if constexpr (SDR_TAP_AUX >= 0 && SPW == 1) v = policy_load16<SDR_TAP_AUX>(eq_src, N * 8, static_cast<unsigned>(k) * 8u);
-                    else v = *reinterpret_cast<const float4*>(eq_src + k);
+                    const float4 v = *reinterpret_cast<const float4*>(eq_src + k);
                     eqv[h * 2] = make_float2(v.x, v.y);
                     eqv[h * 2 + 1] = make_float2(v.z, v.w);
                     if constexpr (!NOWGT) {
-                        float2 u;
-                        if constexpr (SDR_TAP_AUX >= 0 && SPW == 1) u = policy_load8<SDR_TAP_AUX>(wgt_src, N * 4, static_cast<unsigned>(k) * 4u);
-                        else u = *reinterpret_cast<const float2*>(wgt_src + k);
+                        const float2 u = *reinterpret_cast<const float2*>(wgt_src + k);
                         wv[h * 2] = u.x;
                         wv[h * 2 + 1] = u.y;
                     }

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Round 3 evidence on the GPU box (gpurun): rocprofv3 kernel stats + PMC traffic of the default bench, an unprofiled bench
+# line, the Eb/N0 sweep (with its fixed overhead), the kernel table and the rate matrices.  Results land in
+# gpurun_out/evidence; tools/r3_evidence_collect.sh copies the summaries into profiles/.
+cd "${GRAFT_REPO_ROOT:-$PWD}"
+export TMPDIR=/tmp
+OUT=gpurun_out/evidence
+rm -rf $OUT && mkdir -p $OUT
+bash tools/profile_bench.sh > $OUT/profile_bench.log 2>&1 || { echo "profile_bench failed"; tail -5 $OUT/profile_bench.log; exit 1; }
+cp -r gpurun_out/prof $OUT/prof
+echo "profile passes done"
+timeout -k 10 300 python bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err || { echo "bench failed"; exit 1; }
+echo "bench done"
+timeout -k 10 200 python ber_sweep.py > $OUT/ber_sweep.json 2> $OUT/ber_sweep.txt || { echo "ber_sweep failed"; exit 1; }
+timeout -k 10 200 python ber_sweep.py --hard-only > $OUT/ber_sweep_hard_only.json 2> $OUT/ber_sweep_hard_only.txt || { echo "ber_sweep hard failed"; exit 1; }
+echo "sweeps done"
+timeout -k 10 900 python -u tools/kbench.py --repeat 3 --cases $(cat tools/r3_kernel_table_cases.txt) > $OUT/kernel_table.txt 2>&1 || { echo "kbench failed"; exit 1; }
+echo "kernel table done"
+timeout -k 10 900 python -u tools/ratematrix.py > $OUT/rate_matrices.txt 2> $OUT/rate_matrices.err || { echo "ratematrix failed"; exit 1; }
+echo "rate matrices done"
