@@ -522,6 +522,44 @@ def test_hard_decisions_only(ctx, oracle, n, cp, bps):
     assert torch.equal(again.hard, out.hard)
 
 
+@pytest.mark.parametrize("n,cp,bps", [(64, 16, 4), (128, 32, 6), (256, 64, 8), (1024, 256, 4), (1024, 256, 6), (1024, 256, 8), (2048, 512, 6), (4096, 1024, 8),
+                                      (8192, 2048, 6), (1024, 256, 10), (512, 128, 2)])
+def test_hard_decisions_on_boundaries_through_the_fused_kernels(ctx, oracle, n, cp, bps):
+    """Bins that land within an ulp or two of decision boundaries, levels, the grid's edge and far outside it: every
+    subcarrier carries an integer grid value (even = boundary, odd = level) or an outlier, the symbol goes through the
+    oracle's ofdm::tx, and the device transform brings it back to within rounding of where it started.  Half the points
+    therefore fail the slicer's margin test and take the kernels' exact path -- in the hard-only kernel the deferred
+    fix-up of doubtful lanes (rx_fused.hpp), in the every-output and counting kernels the per-point branch -- and must
+    still agree with the reference's scan (modulation.hpp:49-67) bit for bit."""
+    rng = np.random.default_rng(900 + n + bps)
+    mi = (bps + 1) // 2
+    levels = 1 << mi
+    inorm = np.sqrt(np.float32(2.0 * (levels * levels - 1) / 3.0))
+    n_sym = 9 if n <= 1024 else 3
+    grid = rng.integers(-levels - 3, levels + 4, size=(n_sym, n, 2)).astype(np.float64)
+    far = rng.random((n_sym, n, 2)) < 0.01                                   # outliers around the slicer's reach limit
+    grid = np.where(far, rng.choice([-1.0, 1.0], size=grid.shape) * (levels - 1 + rng.choice([30.0, 58.0, 61.0, 62.0, 63.0, 70.0], size=grid.shape)), grid)
+    bins = ((grid[..., 0] + 1j * grid[..., 1]) / float(inorm)).astype(np.complex64)
+    rc, rx = oracle.ofdm_tx(bins, n, cp)                                      # (n_sym, n + cp)
+    assert rc == 0
+    ref = oracle.demod(rx, n, cp, bps, weight=1.5)
+    hard_only = ctx.demod(dev(rx), n, cp, bps, want_llr=False, want_hard=True)
+    assert same(hard_only.hard.cpu().numpy(), ref["hard"])
+    both = ctx.demod(dev(rx), n, cp, bps, llr_weight=1.5, want_llr=True, want_hard=True)
+    assert same(both.hard.cpu().numpy(), ref["hard"]) and same(both.llr.cpu().numpy(), ref["llr"])
+    # and the counting kernel against reference bits that differ from the decisions in known places
+    refbits = ref["hard"].copy()
+    refbits[::7] ^= 0x5A
+    cnt = torch.zeros(8, dtype=torch.int64, device="cuda")
+    ctx.demod(dev(rx), n, cp, bps, llr_weight=1.5, want_llr=True, ref_hard=dev(refbits), counters=cnt)
+    assert int(cnt[0]) == oracle.count_bit_errors(ref["hard"], refbits)
+    # the points really are where the margin test gives up: a tenth of them at least lie within 2^-12 of a boundary
+    u = ref["fft"].astype(np.complex128) * float(inorm)
+    dist = np.minimum(np.abs(np.mod(u.real, 2.0)), np.abs(np.mod(u.imag, 2.0)))
+    dist = np.minimum(dist, 2.0 - dist)
+    assert np.mean(dist < 2.0 ** -12) > 0.1
+
+
 def test_demod_outputs_are_optional(ctx, oracle):
     rx, bits = oracle.link_generate(1024, 256, 4, 3, 0, 4, 0.01)
     ref = oracle.demod(rx, 1024, 256, 4, weight=2.0)
