@@ -28,15 +28,18 @@ if ROOT not in sys.path:
 DEFAULT_MAX_DB = {2: 10, 4: 14, 6: 18, 8: 24}
 
 
-# VALU-issue cost of ONE OFDM symbol in the fused Monte-Carlo kernel at n_fft = 1024, in SIMD cycles:
-# instruction-class counts from rocprofv3 PMC passes (profiles/r2_pmc_instruction_classes_mc_final_65536sym.txt) weighted with the issue cost tools/valubench measured on
-# MI355X (profiles/r2_valubench_issue_cost.txt: VOP1/VOP2 2.15, v_mad_u64_u32 4.6, transcendental 10 cycles
-# per wave64 instruction; the library is built without packed fp32, which would cost 4.1).  Key: bits per subcarrier.
-VALU_ISSUE_CYCLES_PER_SYMBOL_1024 = {1: 9487, 2: 10519, 4: 11933, 6: 13765, 8: 16914, 10: 22251}
-VALU_LANE_INSTR_PER_SYMBOL_1024 = {1: 261448, 2: 292172, 4: 333080, 6: 386437, 8: 479018, 10: 636723}
-# the same for the hard-only bodies (SDR_POINT_HARD_ONLY; profiles/r2_pmc_instruction_classes_mc_hard_only_65536sym.txt)
-VALU_ISSUE_CYCLES_PER_SYMBOL_1024_HARD = {1: 9182, 2: 9765, 4: 9901, 6: 10045, 8: 10193, 10: 10391}
-VALU_LANE_INSTR_PER_SYMBOL_1024_HARD = {1: 253544, 2: 270908, 4: 274954, 6: 279218, 8: 283632, 10: 289512}
+# VALU-issue cost of ONE OFDM symbol in the fused Monte-Carlo kernel at n_fft = 1024, in SIMD cycles: instruction counts
+# from rocprofv3 PMC passes over the round's kernels (tools/r3_mc_pmc.sh, profiles/r3_pmc_instruction_classes_mc_65536sym.txt)
+# priced by tools/mc_issue_tables.py with the issue costs tools/valubench measured on MI355X
+# (profiles/r2_valubench_issue_cost.txt: VOP1/VOP2 2.15, v_mad_u64_u32 4.6, transcendental 10 cycles per wave64
+# instruction; VOP3-encoded instructions, 4.1-4.6 cycles, cannot be told apart by the counters and are priced as VOP2, so
+# the figures are lower bounds; the library is built without packed fp32).  Key: bits per subcarrier.
+# (Round 2's kernels: 9487 ... 22251 cycles, 261448 ... 636723 lane instructions.)
+VALU_ISSUE_CYCLES_PER_SYMBOL_1024 = {1: 8561, 2: 9473, 4: 10563, 6: 12201, 8: 15173, 10: 20235}
+VALU_LANE_INSTR_PER_SYMBOL_1024 = {1: 234962, 2: 262098, 4: 294565, 6: 343299, 8: 431790, 10: 582450}
+# the same for the hard-only bodies (SDR_POINT_HARD_ONLY; profiles/r3_pmc_instruction_classes_mc_hard_only_65536sym.txt)
+VALU_ISSUE_CYCLES_PER_SYMBOL_1024_HARD = {1: 8336, 2: 8887, 4: 8775, 6: 8899, 8: 9037, 10: 9254}
+VALU_LANE_INSTR_PER_SYMBOL_1024_HARD = {1: 228352, 2: 244736, 4: 241399, 6: 245082, 8: 249199, 10: 255656}
 SIMD_CYCLES_PER_S = 256 * 4 * 2.4e9      # 256 CUs x 4 SIMDs at the 2.4 GHz peak engine clock (MI355X_MICROARCH.md)
 # Peak of the vector ALU for unpacked fp32 / int32 work: 157 TFLOP/s of packed FMA = 64 flop per SIMD and cycle, i.e. 32
 # lanes of one operation per SIMD and cycle (a wave64 instruction every two cycles; tools/valubench measures 2.15).
@@ -50,23 +53,27 @@ def algorithmic_lane_ops_per_symbol(n_fft, bps, hard_only=False):
     fp32 / int32 operation on one value; -ffp-contract=off makes a multiply-add two.
       transforms   2 x (N/2) log2 N radix-2 butterflies x 10 operations (four products, six sums: fft.hpp:127-137)
       Philox       N/8 index blocks + N/2 noise blocks, 10 rounds x (2 wide multiplies + 2 three-input xors)
-      Gaussian     per complex sample: ln (9 Horner steps + range reduction), sincos (2 x 4 steps + quadrant), sqrt,
-                   scaling and the addition to the sample (rng.hpp)
+      Gaussian     per complex sample (rng.hpp, table-based since round 3): uniform from 32 bits (3), ln = exponent and
+                   mantissa split, table pair, cubic log1p (17), -2 ln, clamp, sqrt (3), sincos = split of the 24-bit
+                   angle, table pair, two short series and the addition theorems (18), scaling and the addition to
+                   the sample (5)
       mapping      index -> two Gray-decoded levels x norm, and the inverse transform's division by N
-      demapping    x inorm, slicer per axis (nearest), and per axis with L = 2^m levels: L squared distances (2 L),
+      demapping    x inorm, slicer per axis (nearest: fused coordinate, clamp, round, miss, convert) and its two tests,
+                   and per axis with L = 2^m levels: L squared distances (2 L),
                    3 L - 2 m - 4 minima when the aligned-block minima are shared between the bits of the axis (82 at
                    L = 32, qam.hpp axis_llr_level), one difference and one weight product per bit (exact max-log)
-      statistics   per LLR: |.| x 1024, clamp, convert, add; sign errors as one xor + popcount per point
+      statistics   per LLR: scaling, half a packed 16-bit conversion, half a dot product, a sign compare; sign errors as one
+                   xor + popcount per point
     """
     import math
     log2n = int(round(math.log2(n_fft)))
     transforms = 2 * (n_fft // 2) * log2n * 10
     philox = (max(n_fft // 8, 1) + n_fft // 2) * 10 * 4
-    gaussian = n_fft * ((9 * 2 + 12) + (2 * 4 * 2 + 12) + 1 + 3 + 2)
+    gaussian = n_fft * (3 + 17 + 3 + 18 + 5)
     mapping = n_fft * (6 + 2)
     mi = (bps + 1) // 2 if bps > 1 else 1
     mq = bps - mi
-    nearest = n_fft * (2 + sum(6 for m in (mi, mq) if m))
+    nearest = n_fft * (4 + sum(6 for m in (mi, mq) if m))
     llr = 0
     stats = n_fft * 3                                  # xor + popcount + symbol-error compare on the hard decision
     if not hard_only:
@@ -74,7 +81,7 @@ def algorithmic_lane_ops_per_symbol(n_fft, bps, hard_only=False):
             if m:
                 levels = 1 << m
                 llr += n_fft * (2 * levels + max(3 * levels - 2 * m - 4, 0) + 2 * m)
-        stats += n_fft * (bps * 4 + 2)
+        stats += n_fft * (bps * 3 + 2)
     return transforms + philox + gaussian + mapping + nearest + llr + stats
 
 
@@ -104,7 +111,7 @@ def valu_figures(points, counters, n_fft, elapsed, world, hard_only=False):
     if n_fft == 1024 and lanes:
         util = {"frac": cycles / elapsed / (world * SIMD_CYCLES_PER_S), "issue_cycles_per_s": cycles / elapsed, "simd_cycles_per_s": world * SIMD_CYCLES_PER_S,
                 "executed_lane_instructions_per_s": lanes / elapsed, "algorithmic_over_executed": needed / lanes,
-                "note": "kernel's own PMC instruction counts x measured issue cost per class (profiles/r2_valubench_issue_cost.txt); the shader clock under "
+                "note": "kernel's own PMC instruction counts x measured issue cost per class (profiles/r2_valubench_issue_cost.txt; VOP3 forms priced as VOP2, i.e. a lower bound); the shader clock under "
                         "this load is 1.9-2.4 GHz, so frac understates the busy share by up to 20 %; algorithmic_over_executed = how much of what the kernel "
                         "executes the algorithm needs"}
     return roofline, util
