@@ -217,6 +217,9 @@ SIGNATURES = {
 _lib = None
 
 
+OLDER_BUILD = False      # set by tools/abbench.py only: the library about to be loaded may lack the newer entry points
+
+
 def load() -> ctypes.CDLL:
     """Loads libsdr_amd.so (built in-tree by __graft_entry__.build() / sdr_amd/csrc/Makefile)."""
     global _lib
@@ -229,6 +232,8 @@ def load() -> ctypes.CDLL:
         )
     lib = ctypes.CDLL(LIB_PATH)
     for name, (restype, argtypes) in SIGNATURES.items():
+        if OLDER_BUILD and not hasattr(lib, name):
+            continue             # tools/abbench.py timing an earlier round's library against this one
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
         fn.restype = restype
         fn.argtypes = argtypes

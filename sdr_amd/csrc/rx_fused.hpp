@@ -1011,8 +1011,10 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
                             const float ei = y.x * gk.y + y.y * gk.x;
                             y.x = er; y.y = ei;
                             // no weight array: w_k = w0 / |G_k|^2 (= norm^2 |H_k|^2 / N0 for zero-forcing taps), one correctly
-                            // rounded division per bin (uniform branch)
-                            if (p.w_from_taps) w = p.w0 / (gk.x * gk.x + gk.y * gk.y);
+                            // rounded division per bin (uniform branch).  Only where the dispatch can ask for it (the
+                            // instantiation without weight loads and the every-output ones): in the LLR-only kernel WITH a
+                            // weight array the branch, never taken, split every bin's code and cost 1 to 2.5 points.
+                            if constexpr (NOWGT || FULL) if (p.w_from_taps) w = p.w0 / (gk.x * gk.x + gk.y * gk.y);
                         }
                         if constexpr (!NOWGT) {
                             if (p.wgt) {

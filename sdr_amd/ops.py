@@ -188,7 +188,7 @@ class Context:
         fft = out_fft if out_fft is not None else (torch.empty((n_sym, n_fft), dtype=torch.complex64, device=dev) if want_fft else None)
         wt = llr_weight if isinstance(llr_weight, torch.Tensor) else None
         a = DemodArgs()
-        a.struct_size = ctypes.sizeof(DemodArgs)
+        a.struct_size = getattr(self, "demod_struct_size", None) or ctypes.sizeof(DemodArgs)      # (tools/abbench.py: an older build's layout)
         a.n_fft, a.cp, a.mod, a.n_sym = n_fft, cp, bps, n_sym
         a.sym_per_set = sym_per_set
         a.llr_weight0 = 0.0 if wt is not None else float(llr_weight)

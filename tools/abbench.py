@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--cases", nargs="+", required=True)
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--b-round2", action="store_true", help="library B is a round-2 build: pass it the 96-byte sdr_demod_args")
     args = ap.parse_args()
     import torch
     from sdr_amd import capi
@@ -27,9 +28,12 @@ def main():
     def ctx_of(path):
         capi._lib = None
         capi.LIB_PATH = os.path.abspath(path)
+        capi.OLDER_BUILD = args.b_round2 and path == args.lib_b
         c = Context(0)          # binds the freshly loaded library
         return c
     ca, cb = ctx_of(args.lib_a), ctx_of(args.lib_b)
+    if args.b_round2:
+        cb.demod_struct_size = 96      # the round-2 sdr_demod_args (no `flags`)
     assert ca.lib is not cb.lib
     g = torch.Generator(device="cuda").manual_seed(1)
     for case in args.cases:
