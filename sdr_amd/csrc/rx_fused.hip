@@ -102,6 +102,7 @@ int rx_fused_launch(sdr_ctx* ctx, const sdr_demod_args& a, const RxWorkspace* ws
     const bool hard_only = a.d_hard && !a.d_llr && !a.d_fft && !a.d_counters && !a.d_eq && a.mod != 1;   // weights do not matter to nearest()
     int variant = hard_only ? 4 : (full ? 2 : 0) | ((a.d_eq || a.d_llr_weight) ? 1 : 0);
     if (variant == 1 && !a.d_llr_weight) variant = 9;      // LLRs only, taps without a weight array: no weight loads at all
+    if (variant == 1 && !a.d_eq) variant = 3;              // weights without taps: the every-output kernel tests its arrays at run time (the LLR-only one assumes both)
     SDR_TRY(dispatch(ctx, ilog2(a.n_fft), p, static_cast<int>(a.mod), variant));
     if (a.d_counters) SDR_TRY(fold_counter_slots(ctx, p.counters, reinterpret_cast<unsigned long long*>(a.d_counters), a.n_sym * a.n_fft, a.mod, a.n_sym));
     return SDR_OK;

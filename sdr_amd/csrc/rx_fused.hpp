@@ -679,6 +679,10 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
     constexpr int REF_SYM_BYTES = S::REF_SYM_BYTES, CHUNK = S::CHUNK, STG_STRIDE = S::STG_STRIDE;
     constexpr int STG_WAVE_BYTES = S::STG_WAVE_BYTES, STG_OFF = S::STG_OFF, LDS_BYTES = S::LDS_BYTES;
     constexpr bool LATE_TAPS = S::LATE_TAPS, LOOP = S::LOOP;
+    // The LLR-only tap-reading kernels are only dispatched with the arrays they read (taps and weights, or taps alone for
+    // NOWGT; a call with weights alone takes the every-output instantiation): no run-time test of p.eq / p.wgt, which the
+    // compiler turned into three selects per bin with both operands live.
+    constexpr bool TAPS_SURE = EQ && !FULL, WGT_SURE = EQ && !FULL && !NOWGT;
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
     unsigned char* lds_data = lds;
     [[maybe_unused]] idx_t* lds_idx = reinterpret_cast<idx_t*>(lds + S::IDX_OFF);
@@ -780,8 +784,8 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
             if constexpr (PREFETCH_TAPS) {
             constexpr int GO_ = O::kGroupOut;
             const float2* dummy = p.rx + static_cast<size_t>(sym) * in_stride;      // >= N readable float2
-            const float2* eq_src = p.eq ? p.eq + tap_set * N : dummy;
-            [[maybe_unused]] const float* wgt_src = p.wgt ? p.wgt + tap_set * N : reinterpret_cast<const float*>(dummy);
+            const float2* eq_src = (TAPS_SURE || p.eq) ? p.eq + tap_set * N : dummy;
+            [[maybe_unused]] const float* wgt_src = (WGT_SURE || p.wgt) ? p.wgt + tap_set * N : reinterpret_cast<const float*>(dummy);
             static_for<E / GO_>([&](auto Hh) {
                 constexpr int h = Hh;
                 const int k = O::reg_pos(LAST, h * GO_) | pos_last;
@@ -970,8 +974,8 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
             [[maybe_unused]] float epw[(AHEAD > 0 && !NOWGT) ? E : 1];
             [[maybe_unused]] auto epi_load = [&]<int H_>() {
                 const float2* dummy = p.rx + static_cast<size_t>(sym) * in_stride;
-                const float2* eq_src = p.eq ? p.eq + tap_set * N : dummy;
-                [[maybe_unused]] const float* wgt_src = p.wgt ? p.wgt + tap_set * N : reinterpret_cast<const float*>(dummy);
+                const float2* eq_src = (TAPS_SURE || p.eq) ? p.eq + tap_set * N : dummy;
+                [[maybe_unused]] const float* wgt_src = (WGT_SURE || p.wgt) ? p.wgt + tap_set * N : reinterpret_cast<const float*>(dummy);
                 const int k = O::reg_pos(LAST, H_ * GO) | pos_last;
                 if constexpr (GO == 2) {
                     const float4 v = *reinterpret_cast<const float4*>(eq_src + k);
@@ -1003,7 +1007,7 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
                     float2 y = x[h * GO + g];
                     float w = p.w0;
                     if constexpr (EQ) {
-                        if (p.eq) {
+                        if (TAPS_SURE || p.eq) {
                             float2 gk;
                             if constexpr (PREFETCH_TAPS) gk = eqv[h * GO + g];
                             else gk = epi_eq[g];
@@ -1017,7 +1021,7 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
                             if constexpr (NOWGT || FULL) if (p.w_from_taps) w = p.w0 / (gk.x * gk.x + gk.y * gk.y);
                         }
                         if constexpr (!NOWGT) {
-                            if (p.wgt) {
+                            if (WGT_SURE || p.wgt) {
                                 if constexpr (PREFETCH_TAPS) w = wv[h * GO + g];
                                 else w = epi_w[g];
                             }
