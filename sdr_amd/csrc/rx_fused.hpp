@@ -62,6 +62,7 @@ struct RxParams {
     uint32_t w_from_taps;        // no weight array: w_k = w0 / |G_k|^2 instead of the scalar w0 (SDR_DEMOD_WEIGHT_FROM_TAPS)
     uint32_t groups_per_wg;      // consecutive symbol groups handled by one workgroup
     uint32_t xcd_window;         // workgroup-id permutation window (multiple of 8; 0 = none)
+    uint32_t xcd_stagger;        // XCD x starts x * xcd_stagger workgroups into its share of the window (wrapping round)
 };
 
 template <int N, typename F>
@@ -750,7 +751,10 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
         const unsigned long long full = (static_cast<unsigned long long>(gridDim.x) / win) * win;
         if (wg < full) {
             const unsigned long long r = wg % win;
-            wg = wg - r + (r & 7) * (win >> 3) + (r >> 3);
+            const unsigned long long share = win >> 3;
+            unsigned long long j = (r >> 3) + (r & 7) * p.xcd_stagger;      // launch_rx_fused keeps 8 * stagger below the share
+            if (j >= share) j -= share;
+            wg = wg - r + (r & 7) * share + j;
         }
     }
     const unsigned long long grp_begin = wg * p.groups_per_wg;
@@ -1166,11 +1170,13 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
 struct RxTuning {
     long xcd_window = 1L << 30;   // clipped to the grid: every XCD takes one contiguous eighth of the batch
     long lds_pad = 0;             // extra dynamic LDS per workgroup: throttles resident workgroups per CU
+    long xcd_stagger = 0;         // SDR_XCD_STAGGER: XCD x starts x * this many workgroups into its share (phase of the eight streams)
     bool debug = false;
     RxTuning()
     {
         if (const char* v = getenv("SDR_XCD_WINDOW")) xcd_window = atol(v) & ~7L;
         if (const char* v = getenv("SDR_LDS_PAD")) lds_pad = atol(v);
+        if (const char* v = getenv("SDR_XCD_STAGGER")) xcd_stagger = atol(v) < 0 ? 0 : atol(v);
         debug = getenv("SDR_DEBUG") != nullptr;
     }
 };
@@ -1203,6 +1209,7 @@ int launch_rx_fused(sdr_ctx* ctx, const RxParams& p)
     // never wider than the grid: a batch smaller than the window would otherwise run unpermuted
     const unsigned long long win = tune.xcd_window > 0 ? static_cast<unsigned long long>(tune.xcd_window) : 0;
     q.xcd_window = static_cast<uint32_t>(win < (blocks & ~7ull) ? win : (blocks & ~7ull));
+    q.xcd_stagger = (static_cast<unsigned long long>(tune.xcd_stagger) * 8 < (q.xcd_window >> 3)) ? static_cast<uint32_t>(tune.xcd_stagger) : 0u;
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(S::WG_THREADS), static_cast<size_t>(tune.lds_pad > 0 ? tune.lds_pad : 0), ctx->stream, q);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(e, "rx_fused_kernel launch");

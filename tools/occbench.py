@@ -19,6 +19,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", nargs="+", default=["1024:6"])
     ap.add_argument("--pads", type=int, nargs="+", default=[0, 3000, 6656, 8476, 10752, 13677])
+    ap.add_argument("--knob", default="lds_pad", help="sdr_diag_set_tuning knob swept by --pads (lds_pad, xcd_window, xcd_stagger)")
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--symbols", type=int, default=0)
@@ -51,7 +52,7 @@ def main():
         res = {p: [] for p in args.pads}
         for _ in range(args.rounds):
             for p in args.pads:
-                ctx.lib.sdr_diag_set_tuning(b"lds_pad", p)
+                ctx.lib.sdr_diag_set_tuning(args.knob.encode(), p)
                 step()
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -61,8 +62,8 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
                 res[p].append(bytes_sym * n_sym / (e0.elapsed_time(e1) / args.steps) / 1e6)
-        ctx.lib.sdr_diag_set_tuning(b"lds_pad", 0)
-        print(f"case {case:>14s} n_sym {n_sym}: " + "  ".join(f"pad {p}: {statistics.median(v) / 80:5.1f}%" for p, v in res.items()), flush=True)
+        ctx.lib.sdr_diag_set_tuning(args.knob.encode(), (1 << 30) if args.knob == "xcd_window" else 0)
+        print(f"case {case:>14s} n_sym {n_sym}: " + "  ".join(f"{args.knob} {p}: {statistics.median(v) / 80:5.1f}%" for p, v in res.items()), flush=True)
         del rx, out, eq, wgt, hard
         torch.cuda.empty_cache()
     ctx.close()
