@@ -104,6 +104,11 @@ int rx_fused_launch(sdr_ctx* ctx, const sdr_demod_args& a, const RxWorkspace* ws
     int variant = hard_only ? 4 : (full ? 2 : 0) | ((a.d_eq || a.d_llr_weight) ? 1 : 0);
     if (variant == 1 && !a.d_llr_weight) variant = 9;      // LLRs only, taps without a weight array: no weight loads at all
     if (variant == 1 && !a.d_eq) variant = 3;              // weights without taps: the every-output kernel tests its arrays at run time (the LLR-only one assumes both)
+    // LLRs + counters and nothing else: the every-output kernel with its outputs fixed at compile time (RxShape LC).  Same-buffer
+    // A/B against the run-time form (profiles/r3_llr_counters_instantiation_ab.txt): +1.4 to +5.0 points without taps up to
+    // n_fft 2048 and 64-QAM; with taps, from 256-QAM or from n_fft 4096 on the straight-line code needs 17 more registers,
+    // loses a wave per SIMD and 4.6 to 17.5 points -- those keep the run-time form.
+    if (variant == 2 && a.d_llr && a.d_counters && a.d_ref_hard && !a.d_hard && !a.d_fft && a.mod >= 2 && a.mod <= 6 && a.n_fft <= 2048) variant = 10;
     SDR_TRY(dispatch(ctx, ilog2(a.n_fft), p, static_cast<int>(a.mod), variant));
     if (a.d_counters) SDR_TRY(fold_counter_slots(ctx, p.counters, reinterpret_cast<unsigned long long*>(a.d_counters), a.n_sym * a.n_fft, a.mod, a.n_sym));
     return SDR_OK;

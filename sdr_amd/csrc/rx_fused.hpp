@@ -475,7 +475,7 @@ __device__ __forceinline__ void pack_decisions(const idx_t* __restrict__ dec, ui
 // NOWGT (EQ, LLR only): taps without a weight array -- the weight is the scalar w0 or is derived from the tap
 // (RxParams::w_from_taps); no weight load is issued at all (the other EQ instantiations read a dummy source
 // when an array is missing, to keep their loads unconditional).
-template <int LOG2N, int MI, int MQ, bool FULL, bool EQ, bool HARDONLY, bool NOWGT = false>
+template <int LOG2N, int MI, int MQ, bool FULL, bool EQ, bool HARDONLY, bool NOWGT = false, bool LC = false>
 struct RxShape {
     using O = PlanOps<LOG2N>;
     static constexpr int N = O::kN, SPW = O::kSPW;
@@ -483,12 +483,16 @@ struct RxShape {
     static constexpr bool DEMAP = BPS > 0;
     static_assert(!(HARDONLY && (FULL || EQ || !DEMAP)), "HARDONLY is a variant of its own");
     static_assert(!NOWGT || (EQ && !FULL && DEMAP), "taps without a weight array: a form of the LLR-only tap-reading variant");
+    static_assert(!LC || (FULL && DEMAP && MI + MQ > 1), "LLRs + counters with nothing else: a form of the every-output variant");
     static constexpr int WG_THREADS = O::kWG;
     static constexpr int SYM_BYTES = O::max_sym_bytes();
     static constexpr int DATA_BYTES = SYM_BYTES * SPW;
     static constexpr int TW_BYTES = O::kMidCount * 8;
     using idx_t = std::conditional_t<(BPS > 8), uint16_t, uint8_t>;      // one hard decision
-    static constexpr bool HARD_PATH = (FULL || HARDONLY) && DEMAP;       // hard decisions pass through LDS and are packed
+    // LC (round 3): the every-output variant with its outputs fixed at compile time -- LLRs written, hard decisions counted
+    // against reference bits, no packed bits, no bins (the chunked link's receive step, include/sdr_amd.h
+    // sdr_link_chain_c32): none of the per-group run-time tests of the output pointers, no decision staging in LDS.
+    static constexpr bool HARD_PATH = (FULL || HARDONLY) && DEMAP && !LC;       // hard decisions pass through LDS and are packed
     // Hard-only kernels park their decisions in the exchange region, dead after the transform's last
     // exchange read (multi-wave workgroups pay one barrier for it): 10.2 -> 8.2 KiB at N = 1024.
     // The every-output variants do the same from N = 4096 on and at 1024-QAM (behind the staging strips,
@@ -664,14 +668,14 @@ struct RxShape {
 // set, or requested per symbol: RxShape::LATE_TAPS; costs registers, hence a separate instantiation).
 // HARDONLY: packed hard decisions are the only output (the reference's own chain ofdm::rx ->
 // from_constl, lib/inc/ofdm.hpp:37-43 + modulation.hpp:96-112): no LLR arithmetic at all.
-template <int LOG2N, int MI, int MQ, bool FULL, bool EQ, bool HARDONLY = false, bool NOWGT = false>
+template <int LOG2N, int MI, int MQ, bool FULL, bool EQ, bool HARDONLY = false, bool NOWGT = false, bool LC = false>
 __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
-    __attribute__((amdgpu_waves_per_eu(RxShape<LOG2N, MI, MQ, FULL, EQ, HARDONLY, NOWGT>::MIN_WAVES, RxShape<LOG2N, MI, MQ, FULL, EQ, HARDONLY, NOWGT>::MAX_WAVES)))
+    __attribute__((amdgpu_waves_per_eu(RxShape<LOG2N, MI, MQ, FULL, EQ, HARDONLY, NOWGT, LC>::MIN_WAVES, RxShape<LOG2N, MI, MQ, FULL, EQ, HARDONLY, NOWGT, LC>::MAX_WAVES)))
     rx_fused_kernel(const RxParams p)
 {
     using O = PlanOps<LOG2N>;
     using P = typename O::P;
-    using S = RxShape<LOG2N, MI, MQ, FULL, EQ, HARDONLY, NOWGT>;
+    using S = RxShape<LOG2N, MI, MQ, FULL, EQ, HARDONLY, NOWGT, LC>;
     using idx_t = typename S::idx_t;
     constexpr int N = O::kN, E = O::kE, TPS = O::kTPS, SPW = O::kSPW, LAST = O::kLast;
     constexpr int BPS = S::BPS;
@@ -684,6 +688,10 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
     // NOWGT; a call with weights alone takes the every-output instantiation): no run-time test of p.eq / p.wgt, which the
     // compiler turned into three selects per bin with both operands live.
     constexpr bool TAPS_SURE = EQ && !FULL, WGT_SURE = EQ && !FULL && !NOWGT;
+    // which outputs this call produces: run-time pointers, or fixed by the LC instantiation
+    auto want_llr = [&]() { if constexpr (LC) return true; else return p.llr != nullptr; };
+    auto want_fft = [&]() { if constexpr (LC) return false; else return p.fft != nullptr; };
+    auto want_counts = [&]() { if constexpr (LC) return true; else return p.counters != nullptr; };
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
     unsigned char* lds_data = lds;
     [[maybe_unused]] idx_t* lds_idx = reinterpret_cast<idx_t*>(lds + S::IDX_OFF);
@@ -822,7 +830,7 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
         constexpr int REF_PER_THREAD = (REF_WORDS + TPS - 1) / TPS;
         [[maybe_unused]] uint32_t refw[REF_PER_THREAD];
         if constexpr (FULL && DEMAP) {
-            const uint32_t* ref_src = p.ref ? reinterpret_cast<const uint32_t*>(p.ref + static_cast<size_t>(sym) * REF_SYM_BYTES)
+            const uint32_t* ref_src = (LC || p.ref) ? reinterpret_cast<const uint32_t*>(p.ref + static_cast<size_t>(sym) * REF_SYM_BYTES)
                                             : reinterpret_cast<const uint32_t*>(p.rx + static_cast<size_t>(sym) * in_stride);
             static_for<REF_PER_THREAD>([&](auto R) {
                 constexpr int r = R;
@@ -868,7 +876,7 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
         constexpr bool BINS_STAGED = SPW > 1 && O::kWG == 64 && (TPS * GO * 8) % 128 != 0 && (2 * TPS * GO * 8) % 128 == 0
                                      && (E / GO) % 2 == 0 && 64 * GO * 2 * 2 * 4 <= DATA_BYTES;
         if constexpr ((!DEMAP || FULL) && BINS_STAGED) {
-            if (p.fft) {
+            if (want_fft()) {
                 constexpr int CB = GO * 2, NBB = 2;                      // floats per lane and block, blocks per group
                 float* stg = reinterpret_cast<float*>(lds_data);
                 const int lane = tid & 63;
@@ -897,7 +905,7 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
                 });
             }
         } else if constexpr (!DEMAP || FULL) {
-            if (p.fft && active) {
+            if (want_fft() && active) {
                 static_for<E / GO>([&](auto Hh) {
                     constexpr int h = Hh;
                     const int k = O::reg_pos(LAST, h * GO) | pos_last;
@@ -1031,13 +1039,13 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
                             }
                         }
                     }
-                    idx[g] = demap_point<float, MI, MQ, !HARDONLY, HARD_PATH>(y.x, y.y, p.inorm, w, l + g * BPS);
+                    idx[g] = demap_point<float, MI, MQ, !HARDONLY, HARD_PATH || LC>(y.x, y.y, p.inorm, w, l + g * BPS);
                 });
                 if constexpr (STAGE) {
                     // SPW == 1: the wave's block is one contiguous span of the symbol.  SPW > 1 (one
                     // wave = SPW symbols): one contiguous run of TPS * CHUNK floats per symbol, so the
                     // copy is wave-wide and checks the destination symbol, not the lane's own.
-                    if (p.llr && (SPW > 1 || active)) {
+                    if (want_llr() && (SPW > 1 || active)) {
                         // a strip without padding is linear memory: 16-byte vectors may straddle lanes
                         constexpr bool LINEAR = STG_STRIDE == CHUNK * 4 && (64 * CHUNK) % 4 == 0;
                         constexpr int VW = (CHUNK % 4 == 0 || LINEAR) ? 4 : 2;   // floats per vector
@@ -1091,11 +1099,11 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
                         }      // last block of the staged group
                     }
                 } else if constexpr (!HARDONLY) {
-                    if (p.llr && active) store_floats<GO * BPS>(p.llr + (bin0 + k) * BPS, l);
+                    if (want_llr() && active) store_floats<GO * BPS>(p.llr + (bin0 + k) * BPS, l);
                 }
-                if constexpr (HARD_PATH) {
-                    if (HARDONLY || p.hard) static_for<GO>([&](auto G) { constexpr int g = G; lds_idx[slot * N + k + g] = static_cast<idx_t>(idx[g]); });
-                    if constexpr (FULL) if (p.counters && active) {
+                if constexpr (HARD_PATH || LC) {
+                    if constexpr (HARD_PATH) if (HARDONLY || p.hard) static_for<GO>([&](auto G) { constexpr int g = G; lds_idx[slot * N + k + g] = static_cast<idx_t>(idx[g]); });
+                    if constexpr (FULL) if (want_counts() && active) {
                         // GO adjacent points: GO * BPS <= 20 reference bits starting at a multiple of
                         // GO * BPS bits, i.e. inside a four-byte window that starts at the bit's byte
                         static_assert(GO * BPS <= 25, "reference bits of one register group fit a four-byte window");
@@ -1146,7 +1154,7 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
     }
 
     if constexpr (FULL && DEMAP) {
-        if (p.counters) {
+        if (want_counts()) {
             c_bit = wave_sum_u64(c_bit); c_sym = wave_sum_u64(c_sym); c_abs = wave_sum_u64(c_abs);
             c_sign = wave_sum_u64(c_sign);
             if ((tid & 63) == 0) {
@@ -1183,12 +1191,12 @@ struct RxTuning {
 RxTuning& rx_tuning_mutable();      // rx_fused.hip
 inline const RxTuning& rx_tuning() { return rx_tuning_mutable(); }
 
-template <int LOG2N, int MI, int MQ, bool FULL, bool EQ, bool HARDONLY = false, bool NOWGT = false>
+template <int LOG2N, int MI, int MQ, bool FULL, bool EQ, bool HARDONLY = false, bool NOWGT = false, bool LC = false>
 int launch_rx_fused(sdr_ctx* ctx, const RxParams& p)
 {
     using O = PlanOps<LOG2N>;
-    using S = RxShape<LOG2N, MI, MQ, FULL, EQ, HARDONLY, NOWGT>;
-    auto kern = rx_fused_kernel<LOG2N, MI, MQ, FULL, EQ, HARDONLY, NOWGT>;
+    using S = RxShape<LOG2N, MI, MQ, FULL, EQ, HARDONLY, NOWGT, LC>;
+    auto kern = rx_fused_kernel<LOG2N, MI, MQ, FULL, EQ, HARDONLY, NOWGT, LC>;
     const RxTuning& tune = rx_tuning();
     const unsigned long long n_groups = (p.n_sym + O::kSPW - 1) / O::kSPW;
     // One symbol group per workgroup (with the XCD-aware order: +1.5 to +5 points over runs of two
@@ -1200,7 +1208,7 @@ int launch_rx_fused(sdr_ctx* ctx, const RxParams& p)
         int nb = 0;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, S::WG_THREADS, static_cast<size_t>(tune.lds_pad > 0 ? tune.lds_pad : 0));
         if (e != hipSuccess) return fail_hip(e, "hipOccupancyMaxActiveBlocksPerMultiprocessor");
-        fprintf(stderr, "[sdr] rx_fused<%d,%d,%d,%d,%d,%d,%d>: %d threads/WG, %d WG/CU, %d CUs\n", LOG2N, MI, MQ, int(FULL), int(EQ), int(HARDONLY), int(NOWGT), S::WG_THREADS, nb, ctx->num_cu);
+        fprintf(stderr, "[sdr] rx_fused<%d,%d,%d,%d,%d,%d,%d,%d>: %d threads/WG, %d WG/CU, %d CUs\n", LOG2N, MI, MQ, int(FULL), int(EQ), int(HARDONLY), int(NOWGT), int(LC), S::WG_THREADS, nb, ctx->num_cu);
     }
     const unsigned long long blocks = (n_groups + per_wg - 1) / per_wg;
     if (blocks > 0x7FFFFFFFull) return fail(SDR_ERR_UNSUPPORTED, "batch too large for one launch");

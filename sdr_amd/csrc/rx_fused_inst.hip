@@ -15,7 +15,8 @@ namespace sdr {
 
 // mod = 0: FFT only.  variant bit 0: per-subcarrier taps / weights are given (prefetching
 // instantiation); bit 1: every output optional (hard bits, bins, counters); 4: hard bits only;
-// 9: LLRs only, taps without a weight array (no weight loads: scalar weight, or derived from the taps).
+// 9: LLRs only, taps without a weight array (no weight loads: scalar weight, or derived from the taps);
+// 10: LLRs written and hard decisions counted, nothing else, no taps: outputs fixed at compile time (dispatched where it measured faster).
 int SDR_CAT(rx_fused_dispatch_, SDR_LOG2N)(sdr_ctx* ctx, const RxParams& p, int mod, int variant)
 {
     constexpr int L = SDR_LOG2N;
@@ -26,6 +27,7 @@ int SDR_CAT(rx_fused_dispatch_, SDR_LOG2N)(sdr_ctx* ctx, const RxParams& p, int 
         case 9: return launch_rx_fused<L, MI, MQ, false, true, false, true>(ctx, p); \
         case 2: return launch_rx_fused<L, MI, MQ, true, false>(ctx, p);        \
         case 4: return launch_rx_fused<L, MI, MQ, false, false, true>(ctx, p);        \
+        case 10: return launch_rx_fused<L, MI, MQ, true, false, false, false, true>(ctx, p); \
         default: return launch_rx_fused<L, MI, MQ, true, true>(ctx, p);        \
     }
     switch (mod) {
