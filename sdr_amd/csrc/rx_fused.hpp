@@ -634,8 +634,12 @@ struct RxShape {
     // Seven, as a real loop, where the taps' way through L2 weighs most against the symbol's own bytes (same-buffer
     // A/B against the run of two: N = 4096 BPSK +4.9, QPSK +4.2, 1024-QAM +1.3; N = 2048 +2.3 / +1.6 / +0.8);
     // it loses 0.4 to 4.5 points at N <= 1024 and at 4096/16-QAM, and fourteen is no better than seven.
-    static constexpr int RUN = ((LOG2N == 11 || LOG2N == 12) && (BPS <= 2 || BPS == 10)) ? 7 : 2;
-    static constexpr bool LOOP = EQ && !LATE_TAPS && !EQ_STRAIGHT && !EPILOGUE_TAPS;
+    // QPSK at N = 64 / 128 without taps: the smallest symbols of all (512 / 1024 bytes of LLRs), where a workgroup's set-up weighs most --
+    // a run of two (N = 64) or three (N = 128) symbol groups per workgroup: 63.1 -> 72.5 % and 69.0 -> 70.9 % (same-buffer A/B,
+    // profiles/r3_small_n_qpsk_runs_ab.txt); every other small shape (BPSK, 16-QAM up, N = 256) loses 1 to 11 points with runs.
+    static constexpr bool SMALL_LOOP = (LOG2N == 6 || LOG2N == 7) && BPS == 2 && !EQ && !FULL && !HARDONLY;
+    static constexpr int RUN = SMALL_LOOP ? (LOG2N == 6 ? 2 : 3) : ((LOG2N == 11 || LOG2N == 12) && (BPS <= 2 || BPS == 10)) ? 7 : 2;
+    static constexpr bool LOOP = (EQ && !LATE_TAPS && !EQ_STRAIGHT && !EPILOGUE_TAPS) || SMALL_LOOP;
     // The middle pass's twiddle table is written to LDS BEHIND the request for the first symbol's samples: the
     // workgroup then waits for one memory round trip instead of two in a row (table, then samples).  The kernels
     // bound by HBM lose 1.8 to 6.1 points with it at N = 1024 ... 4096 (same-buffer A/B, round 2) and keep the set-up's
