@@ -3,6 +3,7 @@
 // (no reference counterpart), and the generic-size back end of the fused receive path.
 #include "common.hpp"
 #include "kernels.hpp"
+#include "bitpack.hpp"
 #include "qam.hpp"
 
 #include <cmath>
@@ -231,6 +232,35 @@ __global__ void __launch_bounds__(256) from_constl_kernel(const T* __restrict__ 
     }
 }
 
+// from_constl for whole tiles of 1024 fp32 symbols (QPSK ... 256-QAM, 16-byte aligned input): a lane loads two adjacent
+// symbols per instruction (1 KiB contiguous per wave instead of 512 bytes), parks both decisions with one 16-bit LDS
+// store, and the wave packs the tile sixteen decisions per lane (bitpack.hpp: one 16-byte LDS read, BPS / 2 words, one
+// store of 64 * 2 * BPS contiguous bytes per wave).  The ragged rest of an array goes through from_constl_kernel.
+template <int MI, int MQ>
+__global__ void __launch_bounds__(256) from_constl_wide_kernel(const float* __restrict__ sym, size_t n_tiles, float inorm, uint8_t* __restrict__ out)
+{
+    constexpr int BPS = MI + MQ;
+    static_assert(BPS % 2 == 0 && BPS <= 8, "one-byte decisions of an even number of bits");
+    __shared__ __attribute__((aligned(16))) uint8_t strip[4][1024];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint8_t* mine = strip[wave];
+    for (size_t tile = static_cast<size_t>(blockIdx.x) * 4 + wave; tile < n_tiles; tile += static_cast<size_t>(gridDim.x) * 4) {
+        const float4* src = reinterpret_cast<const float4*>(sym + 2 * tile * 1024);
+        float4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = src[j * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const unsigned d0 = demap_point<float, MI, MQ, false, true>(v[j].x, v[j].y, inorm, 0.0f, nullptr);
+            const unsigned d1 = demap_point<float, MI, MQ, false, true>(v[j].z, v[j].w, inorm, 0.0f, nullptr);
+            *reinterpret_cast<uint16_t*>(mine + 2 * (j * 64 + lane)) = static_cast<uint16_t>(d0 | (d1 << 8));
+        }
+        wave_lds_sync();     // one wave: its LDS operations complete in order
+        pack_decisions<1024, BPS, uint8_t>(mine, out + tile * (128 * BPS), lane, 64);
+        wave_lds_sync();
+    }
+}
+
 // Max-log LLRs of a symbol array.  From 6 bits per symbol up, a lane's LLRs (24-40 bytes) go through
 // a per-wave LDS strip so that every store instruction writes 1 KiB contiguous (per-lane chunks cap a
 // copy of this shape at 3 TB/s, tools/membench); the narrower orders store a lane's 4-16 bytes directly.
@@ -416,8 +446,21 @@ int from_constl_dev(sdr_ctx* ctx, bool is_double, int mod, const void* d_sym, si
     const size_t n_bytes = (n_sym * static_cast<size_t>(mod)) / 8;
     if (n_bytes == 0) return SDR_OK;
     if (!d_sym || !d_bytes) return fail(SDR_ERR_INVALID, "null device pointer");
-    const unsigned grid = grid_for(ctx, (n_sym + 7) / 8);
     static_assert(kThreads == 256, "from_constl_kernel is written for four waves per workgroup");
+    // fp32, QPSK ... 256-QAM, aligned buffers: whole tiles of 1024 symbols through the wide kernel, the rest below
+    if (!is_double && mod % 2 == 0 && mod <= 8 && n_sym >= 1024 && reinterpret_cast<uintptr_t>(d_sym) % 16 == 0 && reinterpret_cast<uintptr_t>(d_bytes) % 4 == 0) {
+        const size_t n_tiles = n_sym / 1024;
+        const unsigned wide_grid = grid_for(ctx, n_tiles * 64);
+        dispatch_mod(mod, [&]<int MI, int MQ>() {
+            if constexpr ((MI + MQ) % 2 == 0 && MI + MQ <= 8)
+                hipLaunchKernelGGL((from_constl_wide_kernel<MI, MQ>), dim3(wide_grid), dim3(kThreads), 0, ctx->stream, static_cast<const float*>(d_sym), n_tiles, inorm_in<float>(mod), d_bytes);
+        });
+        SDR_HIP(hipGetLastError());
+        const size_t done = n_tiles * 1024;
+        if (done == n_sym) return SDR_OK;
+        return from_constl_dev(ctx, false, mod, static_cast<const float*>(d_sym) + 2 * done, n_sym - done, d_bytes + done / 8 * static_cast<size_t>(mod));      // < 1024 symbols: the general kernel
+    }
+    const unsigned grid = grid_for(ctx, (n_sym + 7) / 8);
     dispatch_mod(mod, [&]<int MI, int MQ>() {
         if (is_double)
             hipLaunchKernelGGL((from_constl_kernel<double, MI, MQ>), dim3(grid), dim3(kThreads), 0, ctx->stream, static_cast<const double*>(d_sym), n_sym, inorm_in<double>(mod), n_bytes, d_bytes,
