@@ -11,6 +11,15 @@ cp -r gpurun_out/prof $OUT/prof
 echo "profile passes done"
 timeout -k 10 300 python bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err || { echo "bench failed"; exit 1; }
 echo "bench done"
+# the north_star shape (and its plain counterpart) as the headline workload of five fresh processes each: the spread between processes
+for i in 1 2 3 4 5; do
+  timeout -k 10 120 python bench.py --workload fft1024_64qam_eq --no-cpu --no-extra --steps 25 >> $OUT/fresh_process_eq.jsonl 2>> $OUT/fresh_process.err || { echo "fresh-process bench failed"; exit 1; }
+done
+for i in 1 2 3; do
+  timeout -k 10 120 python bench.py --workload fft1024_64qam_1M --no-cpu --no-extra --steps 25 >> $OUT/fresh_process_64qam.jsonl 2>> $OUT/fresh_process.err || { echo "fresh-process bench failed"; exit 1; }
+  timeout -k 10 120 python bench.py --workload fft2048_64qam_eq --no-cpu --no-extra --steps 25 >> $OUT/fresh_process_2048_eq.jsonl 2>> $OUT/fresh_process.err || { echo "fresh-process bench failed"; exit 1; }
+done
+echo "fresh processes done"
 timeout -k 10 200 python ber_sweep.py > $OUT/ber_sweep.json 2> $OUT/ber_sweep.txt || { echo "ber_sweep failed"; exit 1; }
 timeout -k 10 200 python ber_sweep.py --hard-only > $OUT/ber_sweep_hard_only.json 2> $OUT/ber_sweep_hard_only.txt || { echo "ber_sweep hard failed"; exit 1; }
 echo "sweeps done"
