@@ -458,7 +458,7 @@ __device__ __forceinline__ void mc_body(const McWork& p, unsigned char* lds, con
         for (int j = 0; j < E / 8; ++j) {
             const int block = j * TPS + t;
             const Philox4 r = tx_block(p.seed, g, static_cast<uint32_t>(block));
-#pragma unroll 1
+#pragma unroll 2      // two interleaved demappers: +1 to +4 % (stand-alone bodies), sweep +1.3 %; four: the sweep kernel (all six bodies) loses 12 % to registers
             for (int lane = 0; lane < 8; ++lane) {
                 const int pair = lane >> 1;
                 const uint32_t word = pair == 0 ? r.v[0] : pair == 1 ? r.v[1] : pair == 2 ? r.v[2] : r.v[3];
