@@ -2,7 +2,7 @@
 """Fold the FETCH_SIZE / WRITE_SIZE passes of tools/profile_bench.sh into profiles/<tag>_traffic.json.
 
 usage: traffic_json.py gpurun_out/prof profiles/r2_traffic.json
-Per receive kernel of the default bench run: mean counter value per dispatch (KiB), gfx950 correction
+Per receive kernel of the default bench run: median counter value per dispatch (KiB), gfx950 correction
 (MI355X_MICROARCH.md, HBM section: FETCH_SIZE counts half the bytes of wide coalesced reads), bytes per
 launch and per symbol.  bench.py reads the result for roofline.traffic.
 """
@@ -22,7 +22,7 @@ MODS = {1: (1, 0), 2: (1, 1), 4: (2, 2), 6: (3, 3), 8: (4, 4), 10: (5, 5)}
 def kernel_of(name):
     n_fft, _, bps, _, _, with_eq = WORKLOADS[name]
     mi, mq = MODS[bps]
-    return f"{n_fft.bit_length() - 1},{mi},{mq},false,{'true' if with_eq else 'false'},false,false"      # <LOG2N, MI, MQ, FULL, EQ, HARDONLY, NOWGT>
+    return f"{n_fft.bit_length() - 1},{mi},{mq},false,{'true' if with_eq else 'false'},false,false,false"      # <LOG2N, MI, MQ, FULL, EQ, HARDONLY, NOWGT, LC>
 
 
 def collect(root, counter):
@@ -45,8 +45,10 @@ def main():
         k = kernel_of(name)
         if k not in fetch or k not in write:
             continue
-        f = sum(fetch[k]) / len(fetch[k])
-        w = sum(write[k]) / len(write[k])
+        # median, not mean: the same instantiation also serves other launches of the run (the 4 Mi-symbol pass ends with a chunk of
+        # 128 symbols), and the workload's own dispatches are the majority
+        f = sorted(fetch[k])[len(fetch[k]) // 2]
+        w = sorted(write[k])[len(write[k]) // 2]
         total = (2.0 * f + w) * 1024.0
         alg = (8 * n_fft + 4 * n_fft * bps) * n_sym
         kernels[name] = {"kernel": f"sdr::rx_fused_kernel<{k}>", "dispatches": [len(fetch[k]), len(write[k])], "FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w,
