@@ -69,11 +69,12 @@ def algorithmic_bytes_per_symbol(n_fft, bps):
     return 8 * n_fft + 4 * n_fft * bps
 
 
-def make_inputs(ctx, torch, n_fft, cp, bps, n_sym, ebn0_db, with_eq, seed, first_symbol):
+def make_inputs(ctx, torch, n_fft, cp, bps, n_sym, ebn0_db, with_eq, seed, first_symbol, rx=None):
     from sdr_amd.link import noise_sigma, llr_weight, SYMBOLS_PER_FRAME
     sigma = noise_sigma(n_fft, bps, ebn0_db)
     w0 = llr_weight(bps, ebn0_db)
-    rx = torch.empty((n_sym, n_fft + cp), dtype=torch.complex64, device="cuda")
+    if rx is None:
+        rx = torch.empty((n_sym, n_fft + cp), dtype=torch.complex64, device="cuda")
     chan = eq = wgt = None
     per = 0
     if with_eq:
@@ -129,14 +130,38 @@ def launch_stats(launch_ms, bytes_per_launch):
             "hbm_frac_best": frac(v[0]), "hbm_frac_median": frac(med), "hbm_frac_worst": frac(v[-1])}
 
 
-def time_workload(ctx, torch, group, name, steps, warmup, n_sym_override=None):
+def make_arena(ctx, torch, want_gib):
+    """One block of device memory for the sample and LLR buffers of the receive workloads, which sdr_placement_search_c32
+    then places inside it (where the two buffers lie decides 0.74 / 0.77 / 0.80+ of the HBM peak for the
+    same kernel).  None when the device cannot spare 64 GiB: the workloads then use plain allocations."""
+    from sdr_amd.placement import Arena
+    free, _ = torch.cuda.mem_get_info()
+    n_bytes = min(int(want_gib * (1 << 30)), free - (24 << 30))      # room for taps, weights, tables and the allocator's own blocks
+    if n_bytes < (64 << 30):
+        return None
+    try:
+        return Arena(ctx, n_bytes)
+    except torch.cuda.OutOfMemoryError:
+        return None
+
+
+def time_workload(ctx, torch, group, name, steps, warmup, n_sym_override=None, arena=None):
     n_fft, cp, bps, n_sym, ebn0, with_eq = WORKLOADS[name]
     if n_sym_override:
         n_sym = n_sym_override
     world, rank = group.world, group.rank
     first = rank * ((n_sym + 13) // 14) * 14      # whole frames per rank, disjoint global symbol ranges
-    rx, eq, wgt, w0, per = make_inputs(ctx, torch, n_fft, cp, bps, n_sym, ebn0, with_eq, seed=2, first_symbol=first)
-    llr = torch.zeros((n_sym, n_fft, bps), dtype=torch.float32, device="cuda")
+    rx = llr = placement = None
+    if arena is not None and 8 * (n_fft + cp) * n_sym + 4 * n_fft * bps * n_sym + (8 << 20) <= arena.n_bytes:
+        arena.reset()
+        rx, llr = arena.place_demod(n_fft, cp, bps, n_sym)          # the search writes into the arena: inputs are generated after it
+        placement = {"arena_GiB": arena.n_bytes / (1 << 30), "rx_offset_GiB": arena.last["in_offset"] / (1 << 30), "llr_offset_GiB": arena.last["out_offset"] / (1 << 30),
+                     "traffic_model_GBs_at_best_placement": arena.last["model_best_gbs"], "traffic_model_GBs_at_worst_placement": arena.last["model_worst_gbs"],
+                     "what": "sdr_placement_search_c32: sample and LLR buffers as views of one arena, at the offsets where a traffic model of the kernel ran fastest"}
+        llr.zero_()
+    rx, eq, wgt, w0, per = make_inputs(ctx, torch, n_fft, cp, bps, n_sym, ebn0, with_eq, seed=2, first_symbol=first, rx=rx)
+    if llr is None:
+        llr = torch.zeros((n_sym, n_fft, bps), dtype=torch.float32, device="cuda")
 
     def step():
         ctx.demod(rx, n_fft, cp, bps, eq=eq, llr_weight=(wgt if wgt is not None else w0), sym_per_set=per, out_llr=llr)
@@ -188,13 +213,14 @@ def time_workload(ctx, torch, group, name, steps, warmup, n_sym_override=None):
                      "traffic_measured_on_this_build": traffic_same_build,
                      "algorithmic_bytes_per_launch": b_sym * n_sym, "bytes_per_symbol": b_sym, "symbols_per_launch": n_sym, "avg_launch_ms": avg_launch_s * 1e3},
     }
+    res["placement"] = placement or {"what": "plain allocations (torch's caching allocator)"}
     res["buffers"] = {k: hex(v.data_ptr()) for k, v in (("rx", rx), ("llr", llr), ("eq", eq), ("wgt", wgt)) if v is not None}      # placement, for the record
     del rx, llr, eq, wgt
     torch.cuda.empty_cache()
     return res
 
 
-def time_demod_at_stated_size(ctx, torch, name, passes=2):
+def time_demod_at_stated_size(ctx, torch, name, passes=2, arena=None):
     """BASELINE.json configs[2] at its STATED size, demodulator alone: all 4 Mi symbols (86 GB of samples) and their
     taps and weights (7.4 GB) are generated once, untimed, and stay resident; the timed region is the equalised LLR
     kernel over every chunk of symbols, each launch writing the one 12.9 GB LLR buffer (206 GB of LLRs do not fit
@@ -205,9 +231,32 @@ def time_demod_at_stated_size(ctx, torch, name, passes=2):
     sigma = noise_sigma(n_fft, bps, c["ebn0"])
     inv_n0 = bps * 10 ** (c["ebn0"] / 10)
     n_sets = (n_sym + per - 1) // per
-    rx = torch.empty((n_sym, n_fft + cp), dtype=torch.complex64, device="cuda")
-    taps = torch.empty((n_sets, n_fft), dtype=torch.complex64, device="cuda")
-    wgt = torch.empty((n_sets, n_fft), dtype=torch.float32, device="cuda")
+    llr = placement = None
+    resident = 8 * (n_fft + cp) * n_sym + 12 * n_fft * n_sets + 4 * n_fft * bps * chunk
+    if arena is not None and resident + (64 << 20) <= arena.n_bytes:
+        # the LLR buffer where a chunk's output runs fastest; the 86 GB of samples cannot all lie at one best offset and take the
+        # largest gap beside it, taps and weights the next
+        arena.reset()
+        p = arena.search(n_fft, cp, bps, chunk)
+        placement = {"arena_GiB": arena.n_bytes / (1 << 30), "traffic_model_GBs_at_best_placement": p["model_best_gbs"], "traffic_model_GBs_at_worst_placement": p["model_worst_gbs"]}
+        try:
+            llr = arena.take(p["out_offset"], (chunk, n_fft, bps), torch.float32)
+            rx = arena.alloc((n_sym, n_fft + cp), torch.complex64)
+            taps = arena.alloc((n_sets, n_fft), torch.complex64)
+            wgt = arena.alloc((n_sets, n_fft), torch.float32)
+        except MemoryError:                                # the gaps beside the best LLR offset do not hold the samples: one after the other
+            arena.reset()
+            rx = arena.alloc((n_sym, n_fft + cp), torch.complex64)
+            taps = arena.alloc((n_sets, n_fft), torch.complex64)
+            wgt = arena.alloc((n_sets, n_fft), torch.float32)
+            llr = arena.alloc((chunk, n_fft, bps), torch.float32)
+            placement["what"] = "first fit (the gaps beside the best LLR offset were too small for the samples)"
+        placement.update({"llr_offset_GiB": (llr.data_ptr() - arena.mem.data_ptr()) / (1 << 30), "rx_offset_GiB": (rx.data_ptr() - arena.mem.data_ptr()) / (1 << 30)})
+        llr.zero_()
+    else:
+        rx = torch.empty((n_sym, n_fft + cp), dtype=torch.complex64, device="cuda")
+        taps = torch.empty((n_sets, n_fft), dtype=torch.complex64, device="cuda")
+        wgt = torch.empty((n_sets, n_fft), dtype=torch.float32, device="cuda")
     gen_sets = 4096                                        # 57344 symbols per generator call
     for s0 in range(0, n_sets, gen_sets):
         ns = min(gen_sets, n_sets - s0)
@@ -220,7 +269,8 @@ def time_demod_at_stated_size(ctx, torch, name, passes=2):
         ctx.link_generate(n_fft, cp, bps, c["seed"], first, cnt, sigma, chan=chan, sym_per_set=per, want_bits=False, out_rx=rx[first:first + cnt])
     del chan, t, w
     torch.cuda.synchronize()
-    llr = torch.zeros((chunk, n_fft, bps), dtype=torch.float32, device="cuda")
+    if llr is None:
+        llr = torch.zeros((chunk, n_fft, bps), dtype=torch.float32, device="cuda")
     starts = list(range(0, n_sym, chunk))
 
     def one_pass(events=None):
@@ -248,6 +298,7 @@ def time_demod_at_stated_size(ctx, torch, name, passes=2):
            "achieved_GBs": b_sym * n_sym / kernel_s / 1e9, "hbm_frac": b_sym * n_sym / kernel_s / 1e9 / HBM_PEAK_GBS,
            "hbm_frac_incl_tap_bytes": (b_sym + 12.0 * n_fft / per) * n_sym / kernel_s / 1e9 / HBM_PEAK_GBS,
            "per_launch": launch_stats(full, b_sym * chunk),
+           "placement": placement or {"what": "plain allocations (torch's caching allocator)"},
            "what": "equalised LLR kernel (taps + weights per 14-symbol frame) over all resident symbols, chunk by chunk into one reused LLR buffer; generation untimed"}
     del rx, taps, wgt, llr
     torch.cuda.empty_cache()
@@ -335,6 +386,9 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the extra measurements (other configurations, config 3 at 4 Mi symbols, the Eb/N0 sweep)")
     ap.add_argument("--demod-4m", action="store_true", help="only run configs[2]'s demodulator at its stated 4 Mi symbols and print its JSON")
     ap.add_argument("--sweep", action="store_true", help="only run the one-GPU Eb/N0 sweep (configs[4]) and print its JSON")
+    ap.add_argument("--placement", default="search", choices=["search", "default"],
+                    help="search: sample and LLR buffers are views of one arena, placed by sdr_placement_search_c32 (DESIGN.md 7.0); default: plain allocations")
+    ap.add_argument("--arena-gib", type=float, default=200.0, help="size of the arena for --placement search (clipped to what the device has free)")
     args = ap.parse_args()
 
     import torch
@@ -346,8 +400,9 @@ def main():
 
     from sdr_amd.ops import Context
     ctx = Context(local_rank)
+    arena = make_arena(ctx, torch, args.arena_gib) if args.placement == "search" and not (args.sweep or args.chain) else None
     if args.demod_4m or args.sweep:
-        r = time_demod_at_stated_size(ctx, torch, "fft2048_64qam_eq_4M_chain") if args.demod_4m else time_sweep(ctx, torch)
+        r = time_demod_at_stated_size(ctx, torch, "fft2048_64qam_eq_4M_chain", arena=arena) if args.demod_4m else time_sweep(ctx, torch)
         if rank == 0:
             print(json.dumps({"config": {"workload": "fft2048_64qam_eq_4M_demod" if args.demod_4m else "ebn0_sweep_1e10"}, **r}))
         ctx.close()
@@ -361,21 +416,26 @@ def main():
         ctx.close()
         group.close()
         return
-    main_res = time_workload(ctx, torch, group, args.workload, args.steps, args.warmup, args.symbols or None)
-    extra = {"process_group": group.describe()}
+    main_res = time_workload(ctx, torch, group, args.workload, args.steps, args.warmup, args.symbols or None, arena=arena)
+    extra = {"process_group": group.describe(), "placement": main_res["placement"]}
     if world == 1 and not args.no_extra and args.workload == "fft1024_16qam_1M" and not args.symbols:
         # the north_star target shape without and with the equaliser ACTIVE, and the other configurations of
         # BASELINE.json's list, for the record (not bench lines); first launches on fresh buffers run 5-15 % slow,
         # hence 10 untimed launches ahead of each timed region
         for name in ("fft1024_64qam_1M", "fft1024_64qam_eq", "fft2048_64qam_eq", "fft4096_256qam", "fft64_qpsk"):
-            r = time_workload(ctx, torch, group, name, max(10, args.steps // 2), 10)
+            r = time_workload(ctx, torch, group, name, max(10, args.steps // 2), 10, arena=arena)
             extra[name] = {"sym_per_s": r["sym_per_s"], "llr_gbit_per_s": r["sym_per_s"] * r["n_fft"] * r["bps"] / 1e9,
                            "hbm_frac": r["roofline"]["frac"], "achieved_GBs": r["roofline"]["achieved"], "symbols": r["n_sym"],
-                           "equaliser": r["with_eq"], "hbm_traffic_bytes_per_launch": r["roofline"]["traffic"], "per_launch": r["per_launch"]}
+                           "equaliser": r["with_eq"], "hbm_traffic_bytes_per_launch": r["roofline"]["traffic"], "per_launch": r["per_launch"], "placement": r["placement"]}
             if r["with_eq"]:
                 extra[name]["hbm_frac_incl_tap_bytes"] = r["frac_incl_taps"]
                 extra[name]["tap_bytes_per_symbol"] = r["tap_bytes_per_symbol"]
-        extra["fft2048_64qam_eq_4M_demod"] = time_demod_at_stated_size(ctx, torch, "fft2048_64qam_eq_4M_chain")      # configs[2] at its stated size: the demodulator alone
+        extra["fft2048_64qam_eq_4M_demod"] = time_demod_at_stated_size(ctx, torch, "fft2048_64qam_eq_4M_chain", arena=arena)      # configs[2] at its stated size: the demodulator alone
+        if arena is not None:          # the chain and the sweep bring their own workspaces
+            arena.reset()
+            arena.mem = None
+            arena = None
+            torch.cuda.empty_cache()
         extra["fft2048_64qam_eq_4M_chain"] = time_chain(ctx, torch, "fft2048_64qam_eq_4M_chain", 2, 1)               # ... and generated + demodulated + counted
         extra["ebn0_sweep_1e10"] = time_sweep(ctx, torch)                                                            # configs[4] on one GPU
     if main_res.get("copy_shape_gbs"):
@@ -405,7 +465,8 @@ def main():
             "dtype": "f32",
             "data": "synthetic (device frame generator: Philox bits -> QAM -> IFFT+CP -> AWGN)",
             "config": {"workload": args.workload, "n_fft": n_fft, "cp": main_res["cp"], "bits_per_subcarrier": bps,
-                       "symbols_per_gpu": main_res["n_sym"], "sharding": f"independent symbol batches x{world}"},
+                       "symbols_per_gpu": main_res["n_sym"], "sharding": f"independent symbol batches x{world}",
+                       "buffer_placement": "sdr_placement_search_c32 in one arena" if "arena_GiB" in main_res["placement"] else "plain allocations"},
             "llr_gbit_per_s": main_res["sym_per_s"] * n_fft * bps / 1e9,
             "roofline": main_res["roofline"],
             "per_launch": main_res["per_launch"],

@@ -191,6 +191,8 @@ SIGNATURES = {
     "sdr_ofdm_demod_c32": (c_int, [c_void_p, POINTER(DemodArgs)]),
     "sdr_ofdm_demod_host_c32": (c_int, [c_void_p, POINTER(DemodArgs), c_size_t]),
     "sdr_ofdm_demod_noalloc_c32": (c_int, [c_void_p, POINTER(DemodArgs)]),
+    "sdr_placement_search_c32": (c_int, [c_void_p, c_void_p, c_uint64, c_uint32, c_uint32, c_uint32, c_uint64, c_uint64, POINTER(c_uint64), POINTER(c_uint64),
+                                 POINTER(c_float), POINTER(c_float)]),
     "sdr_diag_copy_shape_c32": (c_int, [c_void_p, c_void_p, c_uint32, c_uint32, c_uint32, c_uint64, c_void_p]),
     "sdr_diag_set_tuning": (c_int, [c_char_p, ctypes.c_long]),
     "sdr_zf_taps_c32": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_float, c_void_p, c_void_p]),

@@ -246,6 +246,81 @@ int sdr_ofdm_demod_c32(sdr_ctx* ctx, const sdr_demod_args* args)
     return demap_after_fft(ctx, a, d_fft);
 }
 
+// Placement search (include/sdr_amd.h): the traffic model is copy_shape_launch, the receive kernel's reads and writes
+// in its workgroup order without the arithmetic, timed with events on the context's stream.
+int sdr_placement_search_c32(sdr_ctx* ctx, void* d_arena, uint64_t arena_bytes, uint32_t n_fft, uint32_t cp, uint32_t mod, uint64_t n_sym,
+                             uint64_t step_bytes, uint64_t* in_offset, uint64_t* out_offset, float* best_gbs, float* worst_gbs)
+{
+    SDR_TRY(ensure_device(ctx));
+    if (!d_arena || !in_offset || !out_offset) return fail(SDR_ERR_INVALID, "null pointer");
+    if (!valid_mod(static_cast<int>(mod)) || n_fft < 64 || n_fft > 8192 || (n_fft & (n_fft - 1)) != 0 || cp % 2 != 0 || n_sym == 0)
+        return fail(SDR_ERR_INVALID, "placement search: n_fft 64 ... 8192, even cp, a known modulation, n_sym > 0");
+    if (reinterpret_cast<uintptr_t>(d_arena) % 16 != 0) return fail(SDR_ERR_INVALID, "placement search: arena must be 16-byte aligned");
+    constexpr uint64_t kGrain = 2ull << 20;
+    auto up = [](uint64_t v) { return (v + kGrain - 1) / kGrain * kGrain; };
+    const uint64_t in_bytes = up(n_sym * (static_cast<uint64_t>(n_fft) + cp) * 8);
+    const uint64_t out_bytes = up(n_sym * static_cast<uint64_t>(n_fft) * mod * 4);
+    if (in_bytes + out_bytes > arena_bytes) return fail(SDR_ERR_INVALID, "placement search: arena of %llu bytes, %llu needed", static_cast<unsigned long long>(arena_bytes),
+                                                       static_cast<unsigned long long>(in_bytes + out_bytes));
+    // default step: half the output buffer, so that some candidate straddles every boundary between two regions of the arena whatever
+    // the buffer's size; at most 8 GiB, and at least 1/256 of the arena (a bound on the number of launches)
+    uint64_t step = step_bytes ? up(step_bytes) : up(out_bytes / 2);
+    if (!step_bytes) {
+        if (step > (8ull << 30)) step = 8ull << 30;
+        if (step < up(arena_bytes / 256)) step = up(arena_bytes / 256);
+    }
+    unsigned char* base = static_cast<unsigned char*>(d_arena);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    SDR_HIP(hipEventCreate(&e0));
+    hipError_t ce = hipEventCreate(&e1);
+    if (ce != hipSuccess) { (void)hipEventDestroy(e0); return fail_hip(ce, "hipEventCreate"); }
+    const double alg_bytes = static_cast<double>(n_sym) * (8.0 * n_fft + 4.0 * n_fft * mod);
+    int rc = SDR_OK;
+    auto rate = [&](uint64_t in_off, uint64_t out_off, double* gbs) -> int {
+        SDR_TRY(copy_shape_launch(ctx, base + in_off, n_fft, cp, mod, n_sym, reinterpret_cast<float*>(base + out_off)));      // first touch / warm-up
+        SDR_HIP(hipEventRecord(e0, ctx->stream));
+        for (int i = 0; i < 2; ++i) SDR_TRY(copy_shape_launch(ctx, base + in_off, n_fft, cp, mod, n_sym, reinterpret_cast<float*>(base + out_off)));
+        SDR_HIP(hipEventRecord(e1, ctx->stream));
+        SDR_HIP(hipEventSynchronize(e1));
+        float ms = 0.0f;
+        SDR_HIP(hipEventElapsedTime(&ms, e0, e1));
+        *gbs = ms > 0.0f ? alg_bytes / (ms / 2.0 * 1e-3) / 1e9 : 0.0;
+        return SDR_OK;
+    };
+    auto disjoint = [&](uint64_t in_off, uint64_t out_off) { return in_off + in_bytes <= out_off || out_off + out_bytes <= in_off; };
+    double best = -1.0, worst = 1e30;
+    uint64_t best_in = 0, best_out = 0;
+    // 1. the output at every multiple of the step, the input out of its way (in front of it if it fits there, else behind it)
+    for (uint64_t out_off = 0; rc == SDR_OK && out_off + out_bytes <= arena_bytes; out_off += step) {
+        uint64_t in_off = 0;
+        if (out_off < in_bytes) in_off = out_off + out_bytes;
+        if (in_off + in_bytes > arena_bytes) continue;
+        double g = 0.0;
+        rc = rate(in_off, out_off, &g);
+        if (rc != SDR_OK) break;
+        if (g > best) { best = g; best_in = in_off; best_out = out_off; }
+        if (g < worst) worst = g;
+    }
+    // 2. the input at every multiple of the step beside the best output
+    for (uint64_t in_off = 0; rc == SDR_OK && best >= 0.0 && in_off + in_bytes <= arena_bytes; in_off += step) {
+        if (!disjoint(in_off, best_out) || in_off == best_in) continue;
+        double g = 0.0;
+        rc = rate(in_off, best_out, &g);
+        if (rc != SDR_OK) break;
+        if (g > best) { best = g; best_in = in_off; }
+        if (g < worst) worst = g;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc != SDR_OK) return rc;
+    if (best < 0.0) return fail(SDR_ERR_INVALID, "placement search: no candidate fits the arena");
+    *in_offset = best_in;
+    *out_offset = best_out;
+    if (best_gbs) *best_gbs = static_cast<float>(best);
+    if (worst_gbs) *worst_gbs = static_cast<float>(worst);
+    return SDR_OK;
+}
+
 int sdr_diag_copy_shape_c32(sdr_ctx* ctx, const void* d_rx, uint32_t n_fft, uint32_t cp, uint32_t mod, uint64_t n_sym, float* d_llr)
 {
     SDR_TRY(ensure_device(ctx));

@@ -225,6 +225,17 @@ class Context:
         check(fn(self._h, ctypes.byref(a)))
         return DemodResult(llr, hard, fft)
 
+    # ---- where the buffers lie (sdr_placement_search_c32; no counterpart in the reference) ----
+    def placement_search(self, arena: torch.Tensor, n_fft: int, cp: int, mod, n_sym: int, step_bytes: int = 0):
+        """Fastest (in_offset, out_offset) in bytes for demod()'s sample and LLR buffers inside `arena` (a contiguous uint8 GPU
+        tensor), and the traffic model's rate in GB/s at the best and the worst placement tried.  Overwrites parts of the arena."""
+        _need(arena, torch.uint8, "arena")
+        i, o = ctypes.c_uint64(), ctypes.c_uint64()
+        best, worst = ctypes.c_float(), ctypes.c_float()
+        check(self.lib.sdr_placement_search_c32(self._h, _ptr(arena), arena.numel(), n_fft, cp, mod_bits(mod), n_sym, step_bytes,
+                                                ctypes.byref(i), ctypes.byref(o), ctypes.byref(best), ctypes.byref(worst)))
+        return i.value, o.value, best.value, worst.value
+
     # ---- device frame generator / AWGN / Monte-Carlo link ----
     def copy_shape(self, rx: torch.Tensor, n_fft: int, cp: int, mod, out_llr: torch.Tensor) -> None:
         """Diagnostic: the bytes of demod(LLR only) with no arithmetic (sdr_diag_copy_shape_c32)."""

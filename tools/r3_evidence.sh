@@ -19,6 +19,11 @@ for i in 1 2 3; do
   timeout -k 10 120 python bench.py --workload fft1024_64qam_1M --no-cpu --no-extra --steps 25 >> $OUT/fresh_process_64qam.jsonl 2>> $OUT/fresh_process.err || { echo "fresh-process bench failed"; exit 1; }
   timeout -k 10 120 python bench.py --workload fft2048_64qam_eq --no-cpu --no-extra --steps 25 >> $OUT/fresh_process_2048_eq.jsonl 2>> $OUT/fresh_process.err || { echo "fresh-process bench failed"; exit 1; }
 done
+# the same with plain allocations (--placement default): what the allocator's draw gives
+for i in 1 2 3; do
+  timeout -k 10 120 python bench.py --workload fft1024_64qam_eq --placement default --no-cpu --no-extra --steps 25 >> $OUT/fresh_process_eq_default_placement.jsonl 2>> $OUT/fresh_process.err || { echo "fresh-process bench failed"; exit 1; }
+done
+timeout -k 10 300 python bench.py --placement default --no-cpu > $OUT/bench_line_default_placement.json 2>> $OUT/fresh_process.err || { echo "default-placement bench failed"; exit 1; }
 echo "fresh processes done"
 timeout -k 10 200 python ber_sweep.py > $OUT/ber_sweep.json 2> $OUT/ber_sweep.txt || { echo "ber_sweep failed"; exit 1; }
 timeout -k 10 200 python ber_sweep.py --hard-only > $OUT/ber_sweep_hard_only.json 2> $OUT/ber_sweep_hard_only.txt || { echo "ber_sweep hard failed"; exit 1; }

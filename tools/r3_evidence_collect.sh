@@ -8,10 +8,12 @@ cp $E/prof/fetch/fetch_counter_collection.csv profiles/r3_pmc_fetch_size.csv
 cp $E/prof/write/write_counter_collection.csv profiles/r3_pmc_write_size.csv
 python3 tools/traffic_json.py $E/prof profiles/r3_traffic.json
 cp $E/bench_line.json profiles/r3_bench_line.json
+cp $E/bench_line_default_placement.json profiles/r3_bench_line_default_placement.json
 python3 - <<'PY'
 import json
-out = ["# python bench.py --workload <w> --no-cpu --no-extra --steps 25 in fresh processes, one after the other on one box (tools/r3_evidence.sh): roofline.frac of each"]
-for name in ("fresh_process_eq", "fresh_process_64qam", "fresh_process_2048_eq"):
+out = ["# python bench.py --workload <w> --no-cpu --no-extra --steps 25 in fresh processes, one after the other on one box (tools/r3_evidence.sh): roofline.frac of each",
+       "# (buffers placed by sdr_placement_search_c32 in a 200 GiB arena, bench.py's default; *_default_placement: --placement default, plain allocations)"]
+for name in ("fresh_process_eq", "fresh_process_64qam", "fresh_process_2048_eq", "fresh_process_eq_default_placement"):
     rows = [json.loads(l) for l in open("gpurun_out/evidence/%s.jsonl" % name) if l.startswith("{")]
     out.append("%s (%s): %s" % (name, rows[0]["config"]["workload"], "  ".join("%.4f" % r["roofline"]["frac"] for r in rows)))
 open("profiles/r3_fresh_process_runs.txt", "w").write("\n".join(out) + "\n")
