@@ -22,6 +22,7 @@ namespace sdr {
 #define SDR_DECL_LINK(L) \
     int tx_fused_dispatch_##L(sdr_ctx*, const TxParams&, int); \
     int mc_fused_dispatch_##L(sdr_ctx*, const McParams&, int); \
+    int chain_fused_dispatch_##L(sdr_ctx*, const ChainParams&, int); \
     int sweep_fused_dispatch_##L(sdr_ctx*, const SweepPointDev*, uint32_t, unsigned long long, const float2*, const float2*, unsigned long long, unsigned long long*); \
     int sweep_symbols_per_group_##L();
 SDR_DECL_LINK(6) SDR_DECL_LINK(7) SDR_DECL_LINK(8) SDR_DECL_LINK(9) SDR_DECL_LINK(10) SDR_DECL_LINK(11) SDR_DECL_LINK(12) SDR_DECL_LINK(13)
@@ -54,6 +55,20 @@ int mc_dispatch(sdr_ctx* ctx, unsigned log2n, const McParams& p, int mod)
         case 11: return mc_fused_dispatch_11(ctx, p, mod);
         case 12: return mc_fused_dispatch_12(ctx, p, mod);
         case 13: return mc_fused_dispatch_13(ctx, p, mod);
+        default: return fail(SDR_ERR_UNSUPPORTED, "n_fft = 2^%u has no fused kernel", log2n);
+    }
+}
+int chain_dispatch(sdr_ctx* ctx, unsigned log2n, const ChainParams& p, int mod)
+{
+    switch (log2n) {
+        case 6: return chain_fused_dispatch_6(ctx, p, mod);
+        case 7: return chain_fused_dispatch_7(ctx, p, mod);
+        case 8: return chain_fused_dispatch_8(ctx, p, mod);
+        case 9: return chain_fused_dispatch_9(ctx, p, mod);
+        case 10: return chain_fused_dispatch_10(ctx, p, mod);
+        case 11: return chain_fused_dispatch_11(ctx, p, mod);
+        case 12: return chain_fused_dispatch_12(ctx, p, mod);
+        case 13: return chain_fused_dispatch_13(ctx, p, mod);
         default: return fail(SDR_ERR_UNSUPPORTED, "n_fft = 2^%u has no fused kernel", log2n);
     }
 }
@@ -514,6 +529,15 @@ int link_chain(sdr_ctx* ctx, const sdr_chain_args& a)
     SDR_HIP(hipEventRecord(ctx->chain_consumed[0], main_stream));
     SDR_HIP(hipStreamWaitEvent(gen_stream, ctx->chain_consumed[0], 0));
     const uint64_t n_chunks = (a.n_sym + l.chunk - 1) / l.chunk;
+    // One kernel per chunk (round 3): bits -> constellation -> x channel -> IFFT -> + noise -> FFT -> x tap -> LLRs -> counters with the
+    // samples in LDS only (chain_fused_kernel, link_fused.hpp); the auxiliary stream prepares the next chunk's channel, taps and
+    // weights meanwhile.  The other form: generator and receive kernel with the samples in the workspace.  Same results bit for bit
+    // (tests/test_gpu_chain.py runs both); the choice per shape is from tools/chain_forms.py (profiles/r3_chain_forms.txt): one kernel
+    // wins at N = 2048 (+3 to +8 %, BPSK ... 256-QAM) and 4096 (+3 %), two kernels elsewhere (1 to 7 %: the one-kernel form holds 166 to
+    // 313 registers).  SDR_CHAIN_FORM / sdr_diag_set_tuning("chain_form"): 1 = one kernel, 2 = two kernels, whatever the shape.
+    const long form = rx_tuning().chain_form;
+    const unsigned log2n = ilog2(a.n_fft);
+    const bool fused = !generic_only() && (form == 1 || (form != 2 && (log2n == 11 || log2n == 12) && a.mod <= 8));
     auto generate = [&](uint64_t c) -> int {
         const int b = static_cast<int>(c & 1);
         const uint64_t done = c * l.chunk;
@@ -524,16 +548,19 @@ int link_chain(sdr_ctx* ctx, const sdr_chain_args& a)
         if (c >= 2) SDR_HIP(hipStreamWaitEvent(gen_stream, ctx->chain_consumed[b], 0));     // buffer b was read by chunk c-2
         SDR_TRY(link_channel(ctx, a.n_fft, a.seed, first_set, sets, ws + l.chan[b]));
         SDR_TRY(zf_taps_dev(ctx, static_cast<int>(a.mod), ws + l.chan[b], sets * a.n_fft, a.inv_n0, ws + l.taps[b], reinterpret_cast<float*>(ws + l.wgt[b])));
-        sdr_link_args g = {};
-        g.struct_size = sizeof(sdr_link_args);
-        g.n_fft = a.n_fft; g.cp = a.cp; g.mod = a.mod; g.seed = a.seed;
-        g.first_symbol = a.first_symbol + done; g.n_sym = now; g.sym_per_set = a.sym_per_set; g.sigma = a.sigma;
-        g.d_chan = ws + l.chan[b]; g.d_rx = ws + l.rx[b]; g.d_tx_bits = ws + l.bits[b];
-        // the receive kernel drops the prefix on load (lib/inc/ofdm.hpp:41): the chain's generator neither draws its noise nor stores it
-        SDR_TRY(link_generate(ctx, g, true));
+        if (!fused) {
+            sdr_link_args g = {};
+            g.struct_size = sizeof(sdr_link_args);
+            g.n_fft = a.n_fft; g.cp = a.cp; g.mod = a.mod; g.seed = a.seed;
+            g.first_symbol = a.first_symbol + done; g.n_sym = now; g.sym_per_set = a.sym_per_set; g.sigma = a.sigma;
+            g.d_chan = ws + l.chan[b]; g.d_rx = ws + l.rx[b]; g.d_tx_bits = ws + l.bits[b];
+            // the receive kernel drops the prefix on load (lib/inc/ofdm.hpp:41): the chain's generator neither draws its noise nor stores it
+            SDR_TRY(link_generate(ctx, g, true));
+        }
         SDR_HIP(hipEventRecord(ctx->chain_generated[b], gen_stream));
         return SDR_OK;
     };
+    const float energy = static_cast<float>(grid_energy(static_cast<int>(a.mod)));
     auto run = [&]() -> int {
         SDR_TRY(generate(0));
         for (uint64_t c = 0; c < n_chunks; ++c) {
@@ -542,16 +569,33 @@ int link_chain(sdr_ctx* ctx, const sdr_chain_args& a)
             const uint64_t done = c * l.chunk;
             const uint64_t now = a.n_sym - done < l.chunk ? a.n_sym - done : l.chunk;
             SDR_HIP(hipStreamWaitEvent(main_stream, ctx->chain_generated[b], 0));
-            sdr_demod_args d = {};
-            d.struct_size = sizeof(sdr_demod_args);
-            d.n_fft = a.n_fft; d.cp = a.cp; d.mod = a.mod; d.n_sym = now; d.sym_per_set = a.sym_per_set;
-            d.d_rx = ws + l.rx[b];
-            d.d_eq = ws + l.taps[b];
-            d.d_llr_weight = reinterpret_cast<const float*>(ws + l.wgt[b]);
-            d.d_llr = a.no_llr ? nullptr : reinterpret_cast<float*>(ws + l.llr);
-            d.d_ref_hard = ws + l.bits[b];
-            d.d_counters = a.d_counters;
-            SDR_TRY(rx_fused_launch(ctx, d));
+            if (fused) {
+                ChainParams q = {};
+                const void* twf = nullptr;
+                SDR_TRY(get_twiddles(ctx, a.n_fft, false, false, &twf));
+                SDR_TRY(get_rng_tables(ctx, &q.rng));
+                q.tw_fwd = static_cast<const float2*>(twf);
+                q.chan = reinterpret_cast<const float2*>(ws + l.chan[b]);
+                q.taps = reinterpret_cast<const float2*>(ws + l.taps[b]);
+                q.wgt = reinterpret_cast<const float*>(ws + l.wgt[b]);
+                q.llr = a.no_llr ? nullptr : reinterpret_cast<float*>(ws + l.llr);
+                q.counters = reinterpret_cast<unsigned long long*>(a.d_counters);
+                q.n_sym = now; q.seed = a.seed; q.first_symbol = a.first_symbol + done;
+                q.sigma = a.sigma; q.norm = 1.0f / std::sqrt(energy); q.inorm = std::sqrt(energy);
+                q.sym_per_set = a.sym_per_set;
+                SDR_TRY(chain_dispatch(ctx, ilog2(a.n_fft), q, static_cast<int>(a.mod)));
+            } else {
+                sdr_demod_args d = {};
+                d.struct_size = sizeof(sdr_demod_args);
+                d.n_fft = a.n_fft; d.cp = a.cp; d.mod = a.mod; d.n_sym = now; d.sym_per_set = a.sym_per_set;
+                d.d_rx = ws + l.rx[b];
+                d.d_eq = ws + l.taps[b];
+                d.d_llr_weight = reinterpret_cast<const float*>(ws + l.wgt[b]);
+                d.d_llr = a.no_llr ? nullptr : reinterpret_cast<float*>(ws + l.llr);
+                d.d_ref_hard = ws + l.bits[b];
+                d.d_counters = a.d_counters;
+                SDR_TRY(rx_fused_launch(ctx, d));
+            }
             SDR_HIP(hipEventRecord(ctx->chain_consumed[b], main_stream));
         }
         return SDR_OK;

@@ -359,12 +359,21 @@ struct McWork {
     unsigned long long n_sym;          // symbols of the point handled by this launch
     unsigned long long seed;
     unsigned long long first_symbol;   // global index of the point's first symbol in this launch
-    unsigned long long grp_begin, grp_end;   // symbol groups of the point this workgroup runs
+    unsigned long long grp_begin, grp_end;   // symbol groups of the point this workgroup runs ...
+    unsigned long long grp_stride;     // ... in steps of this many (1: a contiguous run)
     float sigma, w0, norm, inorm;
     bool count_ofdm;                   // this workgroup adds n_sym to counters[4]
+    // FADED bodies only (the chunked link, link.hip): one channel realisation, tap and weight per subcarrier and set of
+    // sym_per_set symbols; LLRs of the launch's symbols (n_sym x N x bps) or null
+    const float2* chan;
+    const float2* taps;
+    const float* wgt;
+    float* llr;
+    unsigned long long first_set;      // set of the launch's first symbol: the arrays start there
+    uint32_t sym_per_set;
 };
 
-template <int LOG2N>
+template <int LOG2N, bool FADED = false>
 struct McLds {
     using O = PlanOps<LOG2N>;
     static constexpr int DATA_BYTES = O::max_sym_bytes() * O::kSPW;
@@ -379,7 +388,8 @@ struct McLds {
     static constexpr int TIME_BYTES = TIME_ALIAS ? 0 : O::kN * 8 * O::kSPW;
     static constexpr int TIME_OFF = TIME_ALIAS ? 0 : DATA_BYTES + TW_BYTES;
     static constexpr int RNG_OFF = (DATA_BYTES + TW_BYTES + TIME_BYTES + 15) & ~15;      // tables of the Gaussian generator (rng.hpp)
-    static constexpr int BYTES = RNG_OFF + kRngBytes + 16;
+    static constexpr int WGT_OFF = RNG_OFF + kRngBytes;                                  // FADED: the symbol's LLR weights for the rolled demapping loop
+    static constexpr int BYTES = WGT_OFF + (FADED ? O::kN * 4 * O::kSPW : 0) + 16;
 };
 
 // generate -> IFFT -> + noise -> FFT -> demap -> count for the symbol groups [grp_begin, grp_end) of
@@ -387,33 +397,58 @@ struct McLds {
 // twiddles) is the caller's, so that one kernel can switch between several bodies.
 // HARD: hard decisions only (the reference's own receive chain ofdm::rx -> from_constl): bit and
 // symbol errors are counted, no LLR is formed and counters 5 and 6 stay untouched.
-template <int LOG2N, int MI, int MQ, bool HARD = false>
+// FADED: the chunked link's body (link.hip: link_chain).  Every subcarrier is multiplied by its set's channel coefficient
+// before the inverse transform (as the generator does, tx_fused_kernel), by its equaliser tap behind the forward transform
+// and demapped with its own LLR weight (as the receive kernel does, rx_fused.hpp), and the LLRs are written out: the
+// samples themselves never exist outside LDS.  Same operations in the same order as generator + receive kernel.
+template <int LOG2N, int MI, int MQ, bool HARD = false, bool FADED = false>
 __device__ __forceinline__ void mc_body(const McWork& p, unsigned char* lds, const FftAddr<LOG2N>& addr, const FftTwiddles<LOG2N>& tw_fwd)
 {
     using O = PlanOps<LOG2N>;
     using A = FftAddr<LOG2N>;
+    using L = McLds<LOG2N, FADED>;
     constexpr int N = O::kN, E = O::kE, TPS = O::kTPS, SPW = O::kSPW;
     constexpr int BPS = MI + MQ;
-    float2* lds_time = reinterpret_cast<float2*>(lds + McLds<LOG2N>::TIME_OFF);
-    const float2* lds_rng = reinterpret_cast<const float2*>(lds + McLds<LOG2N>::RNG_OFF);      // filled by the kernel's set-up
+    static_assert(!(FADED && HARD), "the chunked link forms LLRs");
+    float2* lds_time = reinterpret_cast<float2*>(lds + L::TIME_OFF);
+    const float2* lds_rng = reinterpret_cast<const float2*>(lds + L::RNG_OFF);      // filled by the kernel's set-up
+    [[maybe_unused]] float* lds_wgt = reinterpret_cast<float*>(lds + L::WGT_OFF);
     // aliased time buffer: other waves of the workgroup may still be inside the transform's last exchange
-    constexpr bool ALIAS_SYNC = McLds<LOG2N>::TIME_ALIAS && O::kWG > 64;
+    constexpr bool ALIAS_SYNC = L::TIME_ALIAS && O::kWG > 64;
     const int tid = threadIdx.x;
     const int slot = tid / TPS;
     const int t = tid % TPS;
 
     unsigned long long c_bit = 0, c_sym = 0, c_abs = 0, c_sign = 0, c_n = 0;
-    for (unsigned long long grp = p.grp_begin; grp < p.grp_end; ++grp) {
+    for (unsigned long long grp = p.grp_begin; grp < p.grp_end; grp += p.grp_stride) {
         unsigned long long sym = grp * SPW + slot;
         const bool active = sym < p.n_sym;
         if (!active) sym = p.n_sym - 1;
         const unsigned long long g = p.first_symbol + sym;
 
-        // ---- transmit: indices -> constellation -> IFFT -> /N -> + noise ----
+        // ---- transmit: indices -> constellation [-> x channel] -> IFFT -> /N -> + noise ----
         float2 x[E];
+        [[maybe_unused]] size_t set_off = 0;                       // this symbol's set in the channel / tap / weight arrays
+        if constexpr (FADED) set_off = static_cast<size_t>(g / p.sym_per_set - p.first_set) * N;
+        // FADED: the channel coefficients of the eight elements that share a Philox block are requested together at the block's
+        // first element (a load under the per-element code would be one exposed latency each, tx_fused_kernel); all E held at once,
+        // as the generator does, cost this kernel a wave per SIMD
+        constexpr int lane_mask = TxIndexMap<LOG2N, false>::lane_mask();
+        [[maybe_unused]] float2 hv[8];
         for_each_tx_index<LOG2N, BPS, false>(p.seed, g, addr.in_thread, [&](auto M, uint32_t idx) {
             constexpr int m = M;
-            x[m] = make_float2(level_of<MI>(idx >> MQ) * p.norm, level_of<MQ>(idx & ((1u << MQ) - 1u)) * p.norm);
+            float xr = level_of<MI>(idx >> MQ) * p.norm;
+            float xi = level_of<MQ>(idx & ((1u << MQ) - 1u)) * p.norm;
+            if constexpr (FADED) {
+                if constexpr ((m & lane_mask) == 0)
+                    static_for<8>([&](auto Q) { constexpr int mm = m | O::pdep(Q, lane_mask); hv[Q] = p.chan[set_off + (A::in_reg(mm) | addr.in_thread)]; });
+                constexpr int q = [] { for (int i = 0; i < 8; ++i) if (O::pdep(i, lane_mask) == (m & lane_mask)) return i; return 0; }();
+                const float2 h = hv[q];
+                const float tr = xr * h.x - xi * h.y;
+                const float ti = xr * h.y + xi * h.x;
+                xr = tr; xi = ti;
+            }
+            x[m] = make_float2(xr, xi);
         });
         fft_run<LOG2N, true>(x, lds, addr, tw_fwd);
         // ifft2 divides by N (fft.hpp:200-202); N is a power of two, so the product with the exact
@@ -451,7 +486,36 @@ __device__ __forceinline__ void mc_body(const McWork& p, unsigned char* lds, con
         // i.e. the eight subcarriers block + l*(N/8).  Unrolled in registers, sixteen interleaved
         // demappers (2 x 2^(bps/2) distances each) needed 500+ registers at 64/256-QAM.
         if constexpr (ALIAS_SYNC) __syncthreads();
-        static_for<E>([&](auto M) { constexpr int m = M; lds_time[slot * N + (A::out_reg(m) | addr.pos_last)] = x[m]; });
+        if constexpr (FADED) {
+            // one-tap equaliser, the receive kernel's four products (rx_fused.hpp); taps and weights are requested behind the
+            // transform, eight bins at a time: held across it they cost the kernel half its waves (218 registers against 127)
+            constexpr int TG = E < 8 ? E : 8;
+            static_for<E / TG>([&](auto Q) {
+                constexpr int q = Q;
+                float2 gv[TG];
+                float wv[TG];
+                // (the empty asm pins the requests here: with the address known from the symbol's start the scheduler moved them ahead
+                // of the transform and held 48 registers across it)
+                int pos = addr.pos_last;
+                asm volatile("" : "+v"(pos));
+                static_for<TG>([&](auto I) {
+                    constexpr int m = q * TG + I;
+                    const size_t k = set_off + (A::out_reg(m) | pos);
+                    gv[I] = p.taps[k];
+                    wv[I] = p.wgt[k];
+                });
+                static_for<TG>([&](auto I) {
+                    constexpr int m = q * TG + I;
+                    const int k = slot * N + (A::out_reg(m) | addr.pos_last);
+                    const float er = x[m].x * gv[I].x - x[m].y * gv[I].y;
+                    const float ei = x[m].x * gv[I].y + x[m].y * gv[I].x;
+                    lds_time[k] = make_float2(er, ei);
+                    lds_wgt[k] = wv[I];
+                });
+            });
+        } else {
+            static_for<E>([&](auto M) { constexpr int m = M; lds_time[slot * N + (A::out_reg(m) | addr.pos_last)] = x[m]; });
+        }
         __syncthreads();
         unsigned n_bit = 0, n_sym_err = 0, n_sign = 0, n_abs = 0;   // per symbol and thread: <= 16 points x 10 bits (x 65535 for n_abs)
 #pragma unroll 1
@@ -463,9 +527,21 @@ __device__ __forceinline__ void mc_body(const McWork& p, unsigned char* lds, con
                 const int pair = lane >> 1;
                 const uint32_t word = pair == 0 ? r.v[0] : pair == 1 ? r.v[1] : pair == 2 ? r.v[2] : r.v[3];
                 const uint32_t ref = ((word >> (16u * (lane & 1u))) & 0xFFFFu) & ((1u << BPS) - 1u);
-                const float2 y = lds_time[slot * N + block + lane * (N / 8)];
+                const int bin = block + lane * (N / 8);
+                const float2 y = lds_time[slot * N + bin];
                 float l[BPS];
-                const unsigned idx = demap_point<float, MI, MQ, !HARD, true>(y.x, y.y, p.inorm, p.w0, l);
+                float w = p.w0;
+                if constexpr (FADED) w = lds_wgt[slot * N + bin];
+                const unsigned idx = demap_point<float, MI, MQ, !HARD, true>(y.x, y.y, p.inorm, w, l);
+                if constexpr (FADED) {
+                    // BPS floats per lane, lane-contiguous over the TPS threads of the symbol, as streaming stores (+5 % over plain
+                    // ones; a detour through LDS for 16 bytes per lane was level: the instruction shape is not what the stores cost)
+                    if (p.llr && active) {
+                        float* d_ = p.llr + (static_cast<size_t>(sym) * N + bin) * BPS;
+                        if constexpr (BPS % 2 == 0) static_for<BPS / 2>([&](auto I) { constexpr int i = I; stream_store2(d_ + 2 * i, l[2 * i], l[2 * i + 1]); });
+                        else d_[0] = l[0];
+                    }
+                }
                 const unsigned diff = ref ^ idx;
                 n_bit += __popc(diff);
                 n_sym_err += (diff != 0);
@@ -519,9 +595,70 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) SDR_MC_ATTR mc_fused_kern
     w.n_sym = p.n_sym; w.seed = p.seed; w.first_symbol = p.first_symbol;
     w.grp_begin = static_cast<unsigned long long>(blockIdx.x) * p.groups_per_wg;
     w.grp_end = (w.grp_begin + p.groups_per_wg < n_groups) ? w.grp_begin + p.groups_per_wg : n_groups;
+    w.grp_stride = 1;
     w.sigma = p.sigma; w.w0 = p.w0; w.norm = p.norm; w.inorm = p.inorm;
     w.count_ofdm = blockIdx.x == 0;
     mc_body<LOG2N, MI, MQ>(w, lds, addr, tw_fwd);
+}
+
+// ---- the chunked faded link as ONE kernel per chunk ----------------------------------------------
+struct ChainParams {
+    const float2* tw_fwd;
+    const float2* rng;
+    const float2* chan;          // sets x N, first row = the set of first_symbol
+    const float2* taps;
+    const float* wgt;
+    float* llr;                  // n_sym x N x bps or null
+    unsigned long long* counters;
+    unsigned long long n_sym;
+    unsigned long long seed;
+    unsigned long long first_symbol;
+    float sigma, norm, inorm;
+    uint32_t sym_per_set;
+    uint32_t groups_per_wg;
+};
+
+// Registers: the Monte-Carlo body of the same shape fits four waves per SIMD with two registers to spare (126 of 128 at N = 2048);
+// with the channel, tap and weight values in flight it takes 190.  Asked for three waves (168) it spills eight words and loses a
+// tenth; two waves it is at N >= 2048, three below (no spills there).
+template <int LOG2N, int MI>
+constexpr int chain_min_waves() { return LOG2N <= 10 ? (MI == 5 ? 2 : 3) : LOG2N <= 12 ? 2 : 1; }
+
+template <int LOG2N, int MI, int MQ>
+__global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) __attribute__((amdgpu_waves_per_eu(chain_min_waves<LOG2N, MI>(), 8))) chain_fused_kernel(const ChainParams p)
+{
+    using O = PlanOps<LOG2N>;
+    using L = McLds<LOG2N, true>;
+    constexpr int SPW = O::kSPW;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[L::BYTES];
+    const int tid = threadIdx.x;
+    FftAddr<LOG2N> addr;
+    addr.init(tid % O::kTPS, tid / O::kTPS, O::max_sym_bytes());
+    FftTwiddles<LOG2N> tw_fwd;                   // both directions from the forward table (mc_fused_kernel)
+    tw_fwd.init(p.tw_fwd, reinterpret_cast<float2*>(lds + L::DATA_BYTES), tid, addr);
+    rng_tables_to_lds(p.rng, reinterpret_cast<float2*>(lds + L::RNG_OFF), tid, O::kWG);      // barriers follow before the first use
+    if constexpr (O::kMidCount > 0) __syncthreads();
+
+    const unsigned long long n_groups = (p.n_sym + SPW - 1) / SPW;
+    McWork w;
+    w.counters = p.counters;
+    w.n_sym = p.n_sym; w.seed = p.seed; w.first_symbol = p.first_symbol;
+    // Workgroups are dealt round-robin over the 8 XCDs.  Each XCD takes one contiguous eighth of the symbol groups, and its
+    // workgroups walk it side by side (workgroup i of the XCD: groups i, i + W, i + 2W, ...): what the resident workgroups write at
+    // any moment is one compact window per XCD that moves forward, as in the receive kernel.  With a contiguous run per workgroup
+    // (the Monte-Carlo kernel's split, nothing to write there) the LLRs went out as a thousand streams 6 MB apart and cost the
+    // kernel a fifth of its time.
+    const unsigned long long xcd = blockIdx.x & 7u, lane_wg = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;      // the host launches a multiple of 8
+    const unsigned long long share = (n_groups + 7) / 8;
+    w.grp_begin = xcd * share + lane_wg;
+    w.grp_end = ((xcd + 1) * share < n_groups) ? (xcd + 1) * share : n_groups;
+    w.grp_stride = per_xcd;
+    w.sigma = p.sigma; w.w0 = 0.0f; w.norm = p.norm; w.inorm = p.inorm;
+    w.count_ofdm = blockIdx.x == 0;
+    w.chan = p.chan; w.taps = p.taps; w.wgt = p.wgt; w.llr = p.llr;
+    w.sym_per_set = p.sym_per_set;
+    w.first_set = p.first_symbol / p.sym_per_set;
+    mc_body<LOG2N, MI, MQ, false, true>(w, lds, addr, tw_fwd);
 }
 
 // ---- the whole Eb/N0 sweep in ONE launch --------------------------------------------------------
@@ -569,6 +706,7 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG) SDR_MC_ATTR sweep_fused_k
     w.n_sym = pt.n_sym; w.seed = seed; w.first_symbol = pt.first_symbol;
     w.grp_begin = local * pt.groups_per_block;
     w.grp_end = (w.grp_begin + pt.groups_per_block < pt.n_groups) ? w.grp_begin + pt.groups_per_block : pt.n_groups;
+    w.grp_stride = 1;
     w.sigma = pt.sigma; w.w0 = pt.w0; w.norm = pt.norm; w.inorm = pt.inorm;
     w.count_ofdm = local == 0;
     if (w.grp_begin >= w.grp_end) return;          // uniform; the host never makes such a block
@@ -631,6 +769,23 @@ int launch_sweep_fused(sdr_ctx* ctx, const SweepPointDev* d_pts, uint32_t n_poin
     hipLaunchKernelGGL((sweep_fused_kernel<LOG2N>), dim3(static_cast<unsigned>(blocks)), dim3(O::kWG), 0, ctx->stream, d_pts, n_points, tw, rng, seed, counters);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(e, "sweep_fused_kernel launch");
+    return SDR_OK;
+}
+
+template <int LOG2N, int MI, int MQ>
+int launch_chain_fused(sdr_ctx* ctx, const ChainParams& p)
+{
+    using O = PlanOps<LOG2N>;
+    const unsigned long long n_groups = (p.n_sym + O::kSPW - 1) / O::kSPW;
+    // a resident grid (atomics at the end of long runs, as launch_mc_fused), a multiple of 8 workgroups: see the kernel for the split
+    unsigned long long per_wg = resident_groups_per_wg(ctx, n_groups, 8);
+    if (per_wg < 4) per_wg = n_groups < 4 ? n_groups : 4;
+    unsigned long long blocks = ((n_groups + per_wg - 1) / per_wg + 7) & ~7ull;
+    ChainParams q = p;
+    q.groups_per_wg = 0;
+    hipLaunchKernelGGL((chain_fused_kernel<LOG2N, MI, MQ>), dim3(static_cast<unsigned>(blocks)), dim3(O::kWG), 0, ctx->stream, q);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, "chain_fused_kernel launch");
     return SDR_OK;
 }
 

@@ -43,6 +43,20 @@ int SDR_CAT(mc_fused_dispatch_, SDR_LOG2N)(sdr_ctx* ctx, const McParams& p, int 
     }
 }
 
+int SDR_CAT(chain_fused_dispatch_, SDR_LOG2N)(sdr_ctx* ctx, const ChainParams& p, int mod)
+{
+    constexpr int L = SDR_LOG2N;
+    switch (mod) {
+        case 1: return launch_chain_fused<L, 1, 0>(ctx, p);
+        case 2: return launch_chain_fused<L, 1, 1>(ctx, p);
+        case 4: return launch_chain_fused<L, 2, 2>(ctx, p);
+        case 6: return launch_chain_fused<L, 3, 3>(ctx, p);
+        case 8: return launch_chain_fused<L, 4, 4>(ctx, p);
+        case 10: return launch_chain_fused<L, 5, 5>(ctx, p);
+        default: return fail(SDR_ERR_UNSUPPORTED, "modulation %d has no fused link kernel", mod);
+    }
+}
+
 int SDR_CAT(sweep_fused_dispatch_, SDR_LOG2N)(sdr_ctx* ctx, const SweepPointDev* d_pts, uint32_t n_points, unsigned long long blocks, const float2* tw, const float2* rng,
                                                unsigned long long seed, unsigned long long* counters)
 {

@@ -33,6 +33,7 @@ int rx_set_tuning(const char* name, long value)
     if (n == "lds_pad") t.lds_pad = value;
     else if (n == "xcd_window") t.xcd_window = value & ~7L;
     else if (n == "xcd_stagger") t.xcd_stagger = value < 0 ? 0 : value;
+    else if (n == "chain_form") t.chain_form = value;
     else if (n == "debug") t.debug = value != 0;
     else return fail(SDR_ERR_INVALID, "unknown tuning knob '%s'", name);
     return SDR_OK;

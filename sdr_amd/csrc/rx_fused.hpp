@@ -1122,12 +1122,14 @@ struct RxTuning {
     long xcd_window = 1L << 30;   // clipped to the grid: every XCD takes one contiguous eighth of the batch
     long lds_pad = 0;             // extra dynamic LDS per workgroup: throttles resident workgroups per CU
     long xcd_stagger = 0;         // SDR_XCD_STAGGER: XCD x starts x * this many workgroups into its share (phase of the eight streams)
+    long chain_form = 0;          // SDR_CHAIN_FORM: the chunked link (link.hip) 0 = per shape, 1 = one kernel per chunk, 2 = generator + receive kernel
     bool debug = false;
     RxTuning()
     {
         if (const char* v = getenv("SDR_XCD_WINDOW")) xcd_window = atol(v) & ~7L;
         if (const char* v = getenv("SDR_LDS_PAD")) lds_pad = atol(v);
         if (const char* v = getenv("SDR_XCD_STAGGER")) xcd_stagger = atol(v) < 0 ? 0 : atol(v);
+        if (const char* v = getenv("SDR_CHAIN_FORM")) chain_form = atol(v);
         debug = getenv("SDR_DEBUG") != nullptr;
     }
 };

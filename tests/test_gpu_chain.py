@@ -17,10 +17,20 @@ def test_channel_realisations_bit_exact(ctx, oracle):
     assert abs(np.mean(np.abs(h) ** 2) - 1.0) < 0.02 and abs(h.mean()) < 0.01          # unit variance, zero mean
 
 
-@pytest.mark.parametrize("n,cp,bps,per,n_sym", [(256, 64, 6, 14, 70), (1024, 256, 4, 14, 42), (2048, 512, 6, 14, 28), (64, 16, 2, 3, 50), (4096, 1024, 8, 14, 14)])
-def test_chain_equals_oracle_for_any_chunking(ctx, oracle, n, cp, bps, per, n_sym):
+@pytest.fixture(params=["one_kernel", "two_kernels"])
+def chain_form(request, ctx):
+    """The chunked link runs as ONE kernel per chunk (chain_fused_kernel: samples in LDS only) or as generator + receive kernel
+    with the samples in the workspace; the library picks per shape, the knob forces either.  Same results, bit for bit."""
+    ctx.lib.sdr_diag_set_tuning(b"chain_form", 2 if request.param == "two_kernels" else 1)
+    yield request.param
+    ctx.lib.sdr_diag_set_tuning(b"chain_form", 0)
+
+
+@pytest.mark.parametrize("n,cp,bps,per,n_sym", [(256, 64, 6, 14, 70), (1024, 256, 4, 14, 42), (2048, 512, 6, 14, 28), (64, 16, 2, 3, 50), (4096, 1024, 8, 14, 14),
+                                                (128, 32, 10, 14, 30), (512, 128, 1, 7, 23), (8192, 2048, 6, 2, 5)])
+def test_chain_equals_oracle_for_any_chunking(ctx, oracle, chain_form, n, cp, bps, per, n_sym):
     from sdr_amd.link import noise_sigma
-    ebn0 = {2: 8.0, 4: 12.0, 6: 18.0, 8: 24.0}[bps]
+    ebn0 = {1: 5.0, 2: 8.0, 4: 12.0, 6: 18.0, 8: 24.0, 10: 30.0}[bps]
     sigma = np.float32(noise_sigma(n, bps, ebn0))
     inv_n0 = np.float32(bps * 10 ** (ebn0 / 10))
     g0 = 5 * per
@@ -37,7 +47,7 @@ def test_chain_equals_oracle_for_any_chunking(ctx, oracle, n, cp, bps, per, n_sy
     assert llr2 is None and np.array_equal(cnt2.cpu().numpy().astype(np.uint64), want)
 
 
-def test_chain_many_chunks_equal_one_chunk_and_reuse_the_workspace(ctx):
+def test_chain_many_chunks_equal_one_chunk_and_reuse_the_workspace(ctx, chain_form):
     """FFT-2048 / 64-QAM / 14-symbol frames at 18 dB like configs[2], 16 chunks against one."""
     from sdr_amd.link import noise_sigma
     n, cp, bps, per = 2048, 512, 6, 14
