@@ -432,8 +432,7 @@ def main():
                 extra[name]["tap_bytes_per_symbol"] = r["tap_bytes_per_symbol"]
         extra["fft2048_64qam_eq_4M_demod"] = time_demod_at_stated_size(ctx, torch, "fft2048_64qam_eq_4M_chain", arena=arena)      # configs[2] at its stated size: the demodulator alone
         if arena is not None:          # the chain and the sweep bring their own workspaces
-            arena.reset()
-            arena.mem = None
+            arena.close()
             arena = None
             torch.cuda.empty_cache()
         extra["fft2048_64qam_eq_4M_chain"] = time_chain(ctx, torch, "fft2048_64qam_eq_4M_chain", 2, 1)               # ... and generated + demodulated + counted

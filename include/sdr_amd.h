@@ -186,20 +186,25 @@ int sdr_ofdm_demod_noalloc_c32(sdr_ctx* ctx, const sdr_demod_args* args);
 /* ---- Where the buffers lie in device memory (no counterpart in the reference: it has no device) ------------
  * On MI355X the rate of the receive kernel -- of any kernel that streams a large input into a larger output --
  * depends on WHERE in device memory the two buffers lie, in three steps measured as 0.74 / 0.77 / 0.80-0.83 of the
- * HBM peak for the SAME kernel on the SAME data (DESIGN.md section 7.0, profiles/r3_placement_map.txt): a large
+ * HBM peak for the SAME kernel on the SAME data (DESIGN.md section 5.1, profiles/r3_placement_map.txt): a large
  * allocation is made of separately placed physical regions (32-64 GiB each on the boxes measured); the kernel is
- * slowest when input and output lie in one region, faster when they lie in different ones, and fastest when the
- * OUTPUT straddles two regions, so that the eight XCDs' write streams are spread over both.  Which it gets from a
- * plain allocation is chance (the 0.69-0.77 spread between processes of rounds 2-3).  A caller that owns one large
- * arena can choose: this call times a traffic model of sdr_ofdm_demod_c32 (the same reads and writes in the same
- * workgroup order, no arithmetic) for candidate placements of the two buffers inside [d_arena, d_arena +
- * arena_bytes) -- first the output at every multiple of step_bytes with the input out of its way, then the input at
- * every multiple of step_bytes beside the best output -- and returns the fastest pair of byte offsets (multiples of
- * 2 MiB).  The arena's contents are OVERWRITTEN where outputs were tried; fill the input afterwards.
- * step_bytes = 0 means half the output buffer, at most 8 GiB and at least arena_bytes / 256.  n_fft 64 ... 8192, even cp, arena 16-byte aligned and large enough for both buffers
- * (SDR_ERR_INVALID otherwise).  *best_gbs / *worst_gbs (optional): the model's rate at the best and worst candidate,
- * in GB/s on SURVEY 8(d) bytes.  About (2 * arena_bytes / step_bytes) * 3 launches of the model:
- * a second for 1 Mi symbols of FFT-1024 in a 200 GiB arena. */
+ * slowest when input and output lie in one class of region, faster when they lie in different ones, and fastest
+ * when the OUTPUT straddles two regions, so that the eight XCDs' write streams are spread over both.  Which it
+ * gets from a plain allocation is chance (the 0.69-0.77 spread between processes of rounds 2-3).  A caller that
+ * owns one large arena can choose: this call times a traffic model of sdr_ofdm_demod_c32 (the same reads and
+ * writes in the same workgroup order, no arithmetic) for candidate placements of the two buffers inside
+ * [d_arena, d_arena + arena_bytes) -- first the output at every multiple of step_bytes with the input out of its
+ * way, then the input at every multiple of step_bytes beside the best output -- and returns the fastest pair of
+ * byte offsets (multiples of 2 MiB).
+ *   - The arena's contents are OVERWRITTEN where outputs were tried: fill the input afterwards.
+ *   - The call enqueues on the context's stream and WAITS for its measurements (not for use under stream capture).
+ *   - step_bytes = 0 means half the output buffer, at most 8 GiB and at least arena_bytes / 256.
+ *   - n_fft 64 ... 8192, even cp, a known modulation, n_sym > 0, arena 16-byte aligned and large enough for both
+ *     buffers; SDR_ERR_INVALID otherwise.  For ofdm::rx with bins out (sdr_ofdm_rx_c32) pass mod = SDR_MOD_QPSK:
+ *     8 bytes per subcarrier either way.
+ *   - *best_gbs / *worst_gbs (optional): the model's rate at the best and the worst candidate, in GB/s on
+ *     SURVEY 8(d) bytes.
+ * About (2 * arena_bytes / step_bytes) * 3 launches of the model: a second for 1 Mi symbols of FFT-1024 in 200 GiB. */
 int sdr_placement_search_c32(sdr_ctx* ctx, void* d_arena, uint64_t arena_bytes, uint32_t n_fft, uint32_t cp, uint32_t mod, uint64_t n_sym,
                              uint64_t step_bytes, uint64_t* in_offset, uint64_t* out_offset, float* best_gbs, float* worst_gbs);
 

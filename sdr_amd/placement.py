@@ -45,6 +45,11 @@ class Arena:
     def reset(self) -> None:
         self.taken = []
 
+    def close(self) -> None:
+        """Gives the memory back to torch's allocator; every view handed out must be dead."""
+        self.taken = []
+        self.mem = None
+
     def view(self, offset: int, shape, dtype) -> torch.Tensor:
         n_bytes = _bytes(shape, dtype)
         if offset < 0 or offset + n_bytes > self.n_bytes:
