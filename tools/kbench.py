@@ -24,10 +24,15 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=8, help="fresh buffers run slow for their first 2-3 launches (first touch)")
     ap.add_argument("--repeat", type=int, default=1, help="time every case this many times (interleaved) and report the median")
+    ap.add_argument("--placed", action="store_true", help="sample and LLR buffers of the LLR-writing cases as views of one 180 GiB arena, placed by sdr_placement_search_c32 (DESIGN.md 5.1)")
     args = ap.parse_args()
     import torch
     from sdr_amd.ops import Context
     ctx = Context(0)
+    arena = None
+    if args.placed:
+        from sdr_amd.placement import Arena
+        arena = Arena(ctx, 180 << 30)
     import statistics
     results = {}
     for case in args.cases * args.repeat:
@@ -40,7 +45,15 @@ def main():
         bytes_sym = 8 * n + (4 * n * bps if bps else 8 * n)
         n_sym = args.symbols or max(1024, min(1 << 20, (8 << 30) // (bytes_sym + 8 * cp)))
         g = torch.Generator(device="cuda").manual_seed(1)
-        rx = torch.randn((n_sym, (n + cp) * 2), dtype=torch.float32, device="cuda", generator=g).mul_((2.0 * n) ** -0.5).view(torch.complex64)      # bins of unit average energy, like a received constellation
+        placed_out = None
+        if arena is not None and bps and "nollr" not in parts[2:] and not ("gen" in parts[2:] or "mc" in parts[2:] or "mch" in parts[2:]):
+            arena.reset()
+            rx, placed_out = arena.place_demod(n, cp, bps, n_sym)
+            f = rx.view(torch.float32).view(-1)
+            for i in range(0, f.numel(), 1 << 28):
+                f[i:i + (1 << 28)].normal_(generator=g).mul_((2.0 * n) ** -0.5)
+        else:
+            rx = torch.randn((n_sym, (n + cp) * 2), dtype=torch.float32, device="cuda", generator=g).mul_((2.0 * n) ** -0.5).view(torch.complex64)      # bins of unit average energy, like a received constellation
         eq = wgt = None
         per = 0
         if with_eq:
@@ -77,7 +90,7 @@ def main():
                 else:
                     step = lambda: ctx.link_ber(n, cp, bps, 1, 0, n_sym, 0.01, 1.0, counters=mcnt)
         elif bps:
-            out = None if no_llr else torch.empty((n_sym, n, bps), dtype=torch.float32, device="cuda")
+            out = None if no_llr else (placed_out if placed_out is not None else torch.empty((n_sym, n, bps), dtype=torch.float32, device="cuda"))
             step = lambda: ctx.demod(rx, n, cp, bps, eq=eq, llr_weight=(wgt if wgt is not None else 1.5), sym_per_set=per, out_llr=out, want_llr=not no_llr,
                                      out_hard=hard, ref_hard=ref, counters=cnt)
         elif fft_only:

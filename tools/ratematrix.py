@@ -12,8 +12,11 @@ SIZES = [64, 128, 256, 512, 1024, 2048, 4096, 8192]
 FEW = [64, 256, 1024, 2048, 4096, 8192]
 
 
+PLACED = "--placed" in sys.argv[1:]
+
+
 def run(cases):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kbench.py"), "--cases", *cases], capture_output=True, text=True, check=True).stdout
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kbench.py"), *(["--placed"] if PLACED else []), "--cases", *cases], capture_output=True, text=True, check=True).stdout
     res = {}
     for m in re.finditer(r"case\s+(\S+)\s+n_sym\s+\d+\s+[\d.]+ ms/launch\s+([\d.]+) Msym/s\s+[\d.]+ GB/s\s+([\d.]+) %", out):
         res[m.group(1)] = (float(m.group(3)), float(m.group(2)))
@@ -35,6 +38,9 @@ def matrix(title, sizes, mods, suffix, rates=False):
 
 
 def main():
+    if PLACED:
+        print("# tools/ratematrix.py --placed: as below, but the sample and LLR buffers of every cell are views of one 180 GiB arena at the offsets sdr_placement_search_c32 picks (DESIGN.md 5.1).")
+        print("# The hard-bits-only variant and ofdm::rx keep plain allocations (the first does not depend on placement, tools/poolhard.py).")
     print("# tools/ratematrix.py (tools/kbench.py, one sample per cell: 20 timed launches after 8 warm-up launches, fresh buffers per cell, one box), % of 8 TB/s on SURVEY 8(d) bytes")
     print("# rows: n_fft (cp = n_fft / 4); columns: bits per subcarrier (1 = BPSK ... 10 = 1024-QAM).  Cells move by +-2 to 3 points with the box and the placement of the buffers.\n")
     matrix("fused CP removal + FFT + max-log LLR", SIZES, [1, 2, 4, 6, 8, 10], "")
