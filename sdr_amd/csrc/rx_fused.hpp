@@ -867,13 +867,14 @@ __global__ void __launch_bounds__(PlanOps<LOG2N>::kWG)
                 if (active) pack_decisions<N, BPS, idx_t>(lds_idx + slot * N, p.hard + bin0 * BPS / 8, t, TPS);
             }
         };
-        // Hard decisions alone from 16-QAM up: the margin slicer (qam.hpp) runs over ALL of the thread's bins as one
+        // Hard decisions alone: the margin slicer (qam.hpp) runs over ALL of the thread's bins as one
         // branch-free block -- a per-point branch to the out-of-line test costs eight scalar instructions, two exec
         // round trips and a scheduling barrier per point -- and keeps, per register group, the mask of lanes whose
         // proposal was not clearly inside its cell (one v_cmp into a scalar pair).  Waves with any such lane (about one
         // in four on noise: a point in 4000 is doubtful) then redo exactly those groups for exactly those lanes with the
-        // three-point test / scan and overwrite the parked decisions.
-        constexpr bool SLICE_BLOCK = HARDONLY && (MI >= SDR_FAST_FROM || MQ >= SDR_FAST_FROM) && !SDR_MARGIN_OFF;
+        // three-point test / scan and overwrite the parked decisions.  From 16-QAM up at every size; BPSK and QPSK (whose scan is
+        // four points) from N = 128: QPSK +1 to +3.7 there, -1.3 at N = 64, BPSK level (same-buffer A/B).
+        constexpr bool SLICE_BLOCK = HARDONLY && (MI >= 2 || MQ >= 2 || LOG2N >= 7) && !SDR_MARGIN_OFF;
         if constexpr (SLICE_BLOCK) {
             using MS = MarginSlicer<float, MI, MQ>;
             constexpr int NG = E / GO;

@@ -523,7 +523,8 @@ def test_hard_decisions_only(ctx, oracle, n, cp, bps):
 
 
 @pytest.mark.parametrize("n,cp,bps", [(64, 16, 4), (128, 32, 6), (256, 64, 8), (1024, 256, 4), (1024, 256, 6), (1024, 256, 8), (2048, 512, 6), (4096, 1024, 8),
-                                      (8192, 2048, 6), (1024, 256, 10), (512, 128, 2)])
+                                      (8192, 2048, 6), (1024, 256, 10), (512, 128, 2), (64, 16, 2), (128, 32, 2), (1024, 256, 2), (2048, 512, 2), (4096, 1024, 2),
+                                      (256, 64, 1), (1024, 256, 1), (2048, 512, 1)])
 def test_hard_decisions_on_boundaries_through_the_fused_kernels(ctx, oracle, n, cp, bps):
     """Bins that land within an ulp or two of decision boundaries, levels, the grid's edge and far outside it: every
     subcarrier carries an integer grid value (even = boundary, odd = level) or an outlier, the symbol goes through the
@@ -534,7 +535,8 @@ def test_hard_decisions_on_boundaries_through_the_fused_kernels(ctx, oracle, n, 
     rng = np.random.default_rng(900 + n + bps)
     mi = (bps + 1) // 2
     levels = 1 << mi
-    inorm = np.sqrt(np.float32(2.0 * (levels * levels - 1) / 3.0))
+    lq = 1 << (bps // 2)                                                     # BPSK: one level on Q
+    inorm = np.sqrt(np.float32((levels * levels - 1) / 3.0 + (lq * lq - 1) / 3.0))
     n_sym = 9 if n <= 1024 else 3
     grid = rng.integers(-levels - 3, levels + 4, size=(n_sym, n, 2)).astype(np.float64)
     far = rng.random((n_sym, n, 2)) < 0.01                                   # outliers around the slicer's reach limit

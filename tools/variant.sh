@@ -8,7 +8,7 @@ NAME=$1; EXTRA=$2; shift 2
 OUT=../lib_$NAME
 mkdir -p $OUT
 FLAGS="-O3 -std=c++20 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -I../../include -I. -Wall -Wno-unused-function"
-OBJS=$(ls ../lib/*.o)
+declare -A REPLACED
 pids=()
 for u in "$@"; do
     kind=${u%%:*}; sz=${u##*:}
@@ -16,8 +16,12 @@ for u in "$@"; do
     if [ "$kind" = link ]; then src=link_fused_inst.hip; obj=link_fused_inst_$sz.o; fi
     /opt/rocm/bin/hipcc $FLAGS $EXTRA -DSDR_LOG2N=$sz -c $src -o $OUT/$obj &
     pids+=($!)
-    OBJS=$(echo "$OBJS" | grep -v "/$obj\$")
-    OBJS="$OBJS $OUT/$obj"
+    REPLACED[$obj]=1
+done
+OBJS=""
+for o in ../lib/*.o; do
+    b=$(basename $o)
+    if [ -n "${REPLACED[$b]}" ]; then OBJS="$OBJS $OUT/$b"; else OBJS="$OBJS $o"; fi
 done
 for p in "${pids[@]}"; do wait $p; done
 /opt/rocm/bin/hipcc -shared --offload-arch=gfx950 -o $OUT/libsdr_amd.so $OBJS
