@@ -180,3 +180,39 @@ def test_algorithmic_operation_count_model():
             assert full > hard > 2 * (n // 2) * (n.bit_length() - 1) * 10
     for bps, measured in ber_sweep.VALU_LANE_INSTR_PER_SYMBOL_1024.items():
         assert 0.5 * measured < ber_sweep.algorithmic_lane_ops_per_symbol(1024, bps) < measured
+
+
+def test_arena_bookkeeping_on_cpu_memory():
+    """sdr_amd.placement.Arena: views, first-fit gaps, overlap refusal and reset, on a CPU tensor (the search itself needs the GPU:
+    tests/test_gpu_placement.py)."""
+    import torch
+    from sdr_amd.placement import GRAIN, Arena
+
+    class Stub:
+        torch_device = torch.device("cpu")
+
+    a = Arena(Stub(), 64 * GRAIN + 12345)
+    assert a.n_bytes == 64 * GRAIN                                   # whole grains only
+    x = a.take(4 * GRAIN, (GRAIN // 8 + 1,), torch.complex64)        # one grain and eight bytes: two grains taken
+    assert x.data_ptr() == a.mem.data_ptr() + 4 * GRAIN and a.taken == [(4 * GRAIN, 6 * GRAIN)]
+    with pytest.raises(ValueError):
+        a.take(5 * GRAIN, (16,), torch.float32)                      # inside x
+    with pytest.raises(ValueError):
+        a.take(63 * GRAIN, (GRAIN,), torch.float32)                  # leaves the arena
+    y = a.alloc((3 * GRAIN,), torch.uint8)                           # the gap in front of x holds it
+    assert y.data_ptr() == a.mem.data_ptr()
+    z = a.alloc((2 * GRAIN // 4,), torch.float32)                    # the rest of that gap does not: behind x
+    assert z.data_ptr() == a.mem.data_ptr() + 6 * GRAIN
+    w = a.alloc((GRAIN,), torch.uint8)                               # one grain is left in front of x
+    assert w.data_ptr() == a.mem.data_ptr() + 3 * GRAIN
+    with pytest.raises(MemoryError):
+        a.alloc((57 * GRAIN,), torch.uint8)                          # 56 grains are left behind z
+    assert a.alloc((56 * GRAIN,), torch.uint8).data_ptr() == a.mem.data_ptr() + 8 * GRAIN
+    x.view(torch.float32).fill_(1.0)
+    assert float(a.mem[4 * GRAIN:4 * GRAIN + 4].view(torch.float32)[0]) == 1.0      # views alias the arena
+    a.reset()
+    assert a.alloc((64 * GRAIN,), torch.uint8).data_ptr() == a.mem.data_ptr()
+    with pytest.raises(ValueError):
+        a.place_demod(1024, 256, 4, 16)                              # live views: the search would overwrite them
+    a.close()
+    assert a.mem is None
