@@ -204,6 +204,9 @@ int sdr_ofdm_demod_noalloc_c32(sdr_ctx* ctx, const sdr_demod_args* args);
  *     8 bytes per subcarrier either way.
  *   - *best_gbs / *worst_gbs (optional): the model's rate at the best and the worst candidate, in GB/s on
  *     SURVEY 8(d) bytes.
+ *   - The arena must CONTAIN a boundary between two regions to gain anything: larger than the largest region
+ *     (64 GiB on the boxes measured; 80 GiB was enough, 64 GiB was not).  best_gbs within a few percent of
+ *     worst_gbs says that it does not.
  * About (2 * arena_bytes / step_bytes) * 3 launches of the model: a second for 1 Mi symbols of FFT-1024 in 200 GiB. */
 int sdr_placement_search_c32(sdr_ctx* ctx, void* d_arena, uint64_t arena_bytes, uint32_t n_fft, uint32_t cp, uint32_t mod, uint64_t n_sym,
                              uint64_t step_bytes, uint64_t* in_offset, uint64_t* out_offset, float* best_gbs, float* worst_gbs);
