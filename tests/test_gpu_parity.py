@@ -341,6 +341,9 @@ def test_demod_with_equaliser_sets(ctx, oracle, n, cp, bps):
 
 
 def _random_demod_cases(count=64, seed=20261111):
+    # SDR_SOAK_COUNT / SDR_SOAK_SEED: a longer sweep from another seed (tools/soak.sh), same checks
+    count = int(os.environ.get("SDR_SOAK_COUNT", count))
+    seed = int(os.environ.get("SDR_SOAK_SEED", seed))
     rng = np.random.default_rng(seed)
     cases = []
     for i in range(count):
