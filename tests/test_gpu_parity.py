@@ -535,7 +535,7 @@ def test_hard_decisions_on_boundaries_through_the_fused_kernels(ctx, oracle, n, 
     therefore fail the slicer's margin test and take the kernels' exact path -- in the hard-only kernel the deferred
     fix-up of doubtful lanes (rx_fused.hpp), in the every-output and counting kernels the per-point branch -- and must
     still agree with the reference's scan (modulation.hpp:49-67) bit for bit."""
-    rng = np.random.default_rng(900 + n + bps)
+    rng = np.random.default_rng(900 + n + bps + 100000 * int(os.environ.get("SDR_SOAK_SEED", 0)))
     mi = (bps + 1) // 2
     levels = 1 << mi
     lq = 1 << (bps // 2)                                                     # BPSK: one level on Q
