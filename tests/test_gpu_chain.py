@@ -81,3 +81,21 @@ def test_chain_argument_errors(ctx):
     with pytest.raises(SdrError) as e:
         ctx.link_chain(1024, 256, 4, 1, 0, 28, 14, 14, 0.1, 10.0, workspace=torch.empty(4096, dtype=torch.uint8, device="cuda"))
     assert e.value.code == SDR_ERR_INVALID and "workspace" in e.value.message
+
+
+def test_chain_forms_agree_at_size(ctx):
+    """configs[2]'s shape (FFT-2048, 64-QAM, 14-symbol frames, 18 dB) and configs[3]'s (FFT-4096, 256-QAM) over 57 344 / 14 336 symbols:
+    one kernel per chunk and generator + receive kernel count the same errors and leave the same LLRs in the workspace."""
+    from sdr_amd.link import noise_sigma
+    for n, cp, bps, ebn0, n_sym, chunk in ((2048, 512, 6, 18.0, 57344, 14336), (4096, 1024, 8, 24.0, 14336, 7168)):
+        sigma, inv_n0 = noise_sigma(n, bps, ebn0), bps * 10 ** (ebn0 / 10)
+        res = []
+        for form in (1, 2):
+            ctx.lib.sdr_diag_set_tuning(b"chain_form", form)
+            cnt, llr, _ = ctx.link_chain(n, cp, bps, 11, 28, n_sym, chunk, 14, sigma, inv_n0)
+            torch.cuda.synchronize()
+            res.append((cnt.cpu().numpy().copy(), llr.clone()))
+        ctx.lib.sdr_diag_set_tuning(b"chain_form", 0)
+        assert np.array_equal(res[0][0], res[1][0]) and torch.equal(res[0][1].view(torch.int32), res[1][1].view(torch.int32))
+        c = res[0][0]
+        assert c[4] == n_sym and c[1] == n_sym * n * bps and 0 < c[0] < 0.1 * c[1]
