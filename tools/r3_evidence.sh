@@ -31,4 +31,5 @@ echo "sweeps done"
 timeout -k 10 900 python -u tools/kbench.py --repeat 3 --cases $(cat tools/r3_kernel_table_cases.txt) > $OUT/kernel_table.txt 2>&1 || { echo "kbench failed"; exit 1; }
 echo "kernel table done"
 timeout -k 10 900 python -u tools/ratematrix.py > $OUT/rate_matrices.txt 2> $OUT/rate_matrices.err || { echo "ratematrix failed"; exit 1; }
+timeout -k 10 900 python -u tools/ratematrix.py --placed > $OUT/rate_matrices_placed.txt 2> $OUT/rate_matrices_placed.err || { echo "ratematrix --placed failed"; exit 1; }
 echo "rate matrices done"

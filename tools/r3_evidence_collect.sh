@@ -24,4 +24,5 @@ grep -v amdgpu.ids $E/ber_sweep.txt > profiles/r3_ber_sweep_table.txt
 cp $E/ber_sweep_hard_only.json profiles/r3_ber_sweep_hard_only.json
 (echo "# tools/kbench.py --repeat 3 (8 untimed + 20 timed launches per repeat, fresh buffers, bins of unit average energy), kernels at the end of round 3; case = n_fft:bps[:eq][:hard][:cnt][:nollr][:gen][:mc], bps 0 = bins out, fft = in-place fft2; gen: bytes = samples written; mc: LLR-equivalent bytes (nothing touches HBM)"; grep "median" $E/kernel_table.txt) > profiles/r3_kernel_table.txt
 grep -v amdgpu.ids $E/rate_matrices.txt > profiles/r3_rate_matrices.txt
+grep -v amdgpu.ids $E/rate_matrices_placed.txt > profiles/r3_rate_matrices_placed.txt
 ls -la profiles/r3_*
