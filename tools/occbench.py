@@ -23,10 +23,15 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--symbols", type=int, default=0)
+    ap.add_argument("--placed", action="store_true", help="sample and LLR buffers placed by sdr_placement_search_c32 in a 180 GiB arena")
     args = ap.parse_args()
     import torch
     from sdr_amd.ops import Context
     ctx = Context(0)
+    arena = None
+    if args.placed:
+        from sdr_amd.placement import Arena
+        arena = Arena(ctx, 180 << 30)
     for case in args.cases:
         parts = case.split(":")
         n, bps = int(parts[0]), int(parts[1])
@@ -35,7 +40,15 @@ def main():
         bytes_sym = 8 * n + (0 if no_llr else 4 * n * bps) + (n * bps // 8 if with_hard else 0)
         n_sym = args.symbols or max(1024, min(1 << 20, (8 << 30) // (bytes_sym + 8 * cp)))
         g = torch.Generator(device="cuda").manual_seed(1)
-        rx = torch.randn((n_sym, (n + cp) * 2), dtype=torch.float32, device="cuda", generator=g).mul_((2.0 * n) ** -0.5).view(torch.complex64)
+        placed_out = None
+        if arena is not None and not no_llr:
+            arena.reset()
+            rx, placed_out = arena.place_demod(n, cp, bps, n_sym)
+            f = rx.view(torch.float32).view(-1)
+            for i in range(0, f.numel(), 1 << 28):
+                f[i:i + (1 << 28)].normal_(generator=g).mul_((2.0 * n) ** -0.5)
+        else:
+            rx = torch.randn((n_sym, (n + cp) * 2), dtype=torch.float32, device="cuda", generator=g).mul_((2.0 * n) ** -0.5).view(torch.complex64)
         eq = wgt = None
         per = 0
         if with_eq:
@@ -43,7 +56,7 @@ def main():
             n_sets = (n_sym + per - 1) // per
             eq = torch.randn((n_sets, n * 2), dtype=torch.float32, device="cuda", generator=g).view(torch.complex64)
             wgt = torch.rand((n_sets, n), dtype=torch.float32, device="cuda", generator=g)
-        out = None if no_llr else torch.empty((n_sym, n, bps), dtype=torch.float32, device="cuda")
+        out = None if no_llr else (placed_out if placed_out is not None else torch.empty((n_sym, n, bps), dtype=torch.float32, device="cuda"))
         hard = torch.empty(n_sym * n * bps // 8, dtype=torch.uint8, device="cuda") if with_hard else None
         step = lambda: ctx.demod(rx, n, cp, bps, eq=eq, llr_weight=(wgt if wgt is not None else 1.5), sym_per_set=per, out_llr=out, want_llr=not no_llr, out_hard=hard)
         for _ in range(6):
